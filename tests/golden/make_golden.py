@@ -1,0 +1,456 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by IMPORTING the reference (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|all]
+
+The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
+the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
+``ray`` is not installed here, so an in-process stub module with an identity ``remote`` decorator
+is registered before ``utilities``/``main`` are imported -- nothing else of the
+reference is altered.  Harness-side conventions: the reference is handed a legal
+list SORTED by action index wherever list order matters (root expansion, noise, select_action),
+and every random number it would draw from ``np.random`` is recorded and stored by action index.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+ray = types.ModuleType("ray")
+
+
+def _remote(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+ray.remote = _remote
+ray.init = lambda *a, **k: None
+ray.put = lambda x: x
+ray.get = lambda x: x
+sys.modules["ray"] = ray
+sys.path.insert(0, "/root/reference")
+
+import main as M  # noqa: E402  (the reference; sets OMP_NUM_THREADS=1 before torch)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import refspec as R  # noqa: E402
+
+SEED = 1261
+
+
+# ------------------------------------------------------------------------------------------------
+# env traces
+# ------------------------------------------------------------------------------------------------
+def env_state(env):
+    white = black = 0
+    for r in range(8):
+        for c in range(8):
+            v = int(env.board[r, c])
+            if v == 1:
+                white |= 1 << (r * 8 + c)
+            elif v == -1:
+                black |= 1 << (r * 8 + c)
+    legal = 0
+    pas = 0
+    for a in env.legal_actions:
+        if a.index == 64:
+            pas = 1
+        else:
+            legal |= 1 << int(a.index)
+    return white, black, env.player.value, env.steps, int(env.done), legal, pas
+
+
+def play_random_game(args):
+    game_id, seed, voluntary_pass, n_steps = args
+    env = M.Environment()
+    rec = [env_state(env)]
+    actions, rewards = [], []
+    h = R.digest_step(0, *rec[0][:5], 0, *rec[0][5:])
+    for step in range(n_steps):
+        w, b, tp, st, dn, legal, pas = rec[-1]
+        a = R.playout_action(seed, game_id, step, legal)
+        if voluntary_pass and (R.playout_rand(seed ^ 0x5555, game_id, step) & 7) == 0:
+            a = 64  # reversi.py:135-139 accepts a pass without any legality check
+        _, reward, done = env.step(M.Action(a, env.player))
+        s = env_state(env)
+        assert s[4] == int(done)
+        rec.append(s)
+        actions.append(a)
+        rewards.append(int(reward))
+        h = R.digest_step(h, s[0], s[1], s[2], s[3], s[4], int(reward), s[5], s[6])
+    return game_id, rec, actions, rewards, h
+
+
+def gen_env():
+    import multiprocessing as mp
+    n_full, n_dig, n_vol = 128, 4096, 512
+    with mp.Pool(8) as pool:
+        dig = pool.map(play_random_game, [(g, SEED, 0, 60) for g in range(n_dig)], chunksize=16)
+        vol = pool.map(play_random_game, [(g, SEED + 1, 1, 60) for g in range(n_vol)], chunksize=16)
+    out = {"seed": np.uint64(SEED)}
+
+    def pack_full(games, prefix):
+        n = len(games)
+        W = np.zeros((n, 61), np.uint64); B = np.zeros((n, 61), np.uint64)
+        L = np.zeros((n, 61), np.uint64)
+        TP = np.zeros((n, 61), np.int8); ST = np.zeros((n, 61), np.uint8)
+        DN = np.zeros((n, 61), np.uint8); PS = np.zeros((n, 61), np.uint8)
+        A = np.zeros((n, 60), np.uint8); RW = np.zeros((n, 60), np.int8)
+        for i, (_, rec, actions, rewards, _) in enumerate(games):
+            for t, s in enumerate(rec):
+                W[i, t], B[i, t], TP[i, t], ST[i, t], DN[i, t], L[i, t], PS[i, t] = s
+            A[i] = actions
+            RW[i] = rewards
+        for k, v in dict(white=W, black=B, legal=L, to_play=TP, steps=ST, done=DN, pass_flag=PS,
+                         actions=A, rewards=RW).items():
+            out[prefix + k] = v
+
+    pack_full(dig[:n_full], "full_")
+    pack_full(vol[:64], "volfull_")
+    for prefix, games in (("dig_", dig), ("vol_", vol)):
+        out[prefix + "actions"] = np.array([g[2] for g in games], np.uint8)
+        out[prefix + "rewards_last"] = np.array([g[3][-1] for g in games], np.int8)
+        out[prefix + "digest"] = np.array([g[4] for g in games], np.uint64)
+        fin = [g[1][-1] for g in games]
+        out[prefix + "final_white"] = np.array([f[0] for f in fin], np.uint64)
+        out[prefix + "final_black"] = np.array([f[1] for f in fin], np.uint64)
+        out[prefix + "final_to_play"] = np.array([f[2] for f in fin], np.int8)
+        out[prefix + "final_done"] = np.array([f[4] for f in fin], np.uint8)
+    # coverage the survey asks for: report it so a reader can see the cases exist
+    acts = out["dig_actions"]
+    n_pass = (acts == 64).sum(1)
+    print("env: games with >=1 pass:", int((n_pass > 0).sum()), " >=2 passes:", int((n_pass > 1).sum()),
+          " pass as 60th step (done stays 0):", int((acts[:, 59] == 64).sum()),
+          " not done at end:", int((out["dig_final_done"] == 0).sum()))
+    assert (acts[:, 59] == 64).sum() > 0 and (n_pass > 1).sum() > 0
+    np.savez_compressed(os.path.join(HERE, "env_traces.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# MCTS traces
+# ------------------------------------------------------------------------------------------------
+class HashNetwork:
+    """duck-typed stand-in for network.Network (value (1,1), policy (1,65), hidden (1,8,8,8))."""
+
+    def __init__(self, mode="hash"):
+        self.mode = mode
+        self.calls = []  # (parent_h, action_code)
+
+    def _out(self, h):
+        v, p = R.hashnet_outputs(h, self.mode)
+        return (torch.tensor([[v]], dtype=torch.float32), torch.from_numpy(p).unsqueeze(0),
+                torch.from_numpy(R.hashnet_hidden(h)).reshape(1, 8, 8, 8))
+
+    def initial_inference(self, image):
+        return self._out(R.hashnet_image_hash(image.numpy()))
+
+    def recurrent_inference(self, hidden, action):
+        h = R.hashnet_h_from_hidden(hidden.numpy())
+        code = R.hashnet_action_code(action.numpy())
+        self.calls.append((h, code))
+        return self._out(R.hashnet_step(h, code))
+
+
+class RecordingNetwork:
+    """wraps the reference's real Network and records every (value, policy) it returns."""
+
+    def __init__(self, net):
+        self.net = net
+        self.values, self.policies = [], []
+
+    def initial_inference(self, image):
+        with torch.no_grad():
+            return self.net.initial_inference(image)
+
+    def recurrent_inference(self, hidden, action):
+        with torch.no_grad():
+            out = self.net.recurrent_inference(hidden, action)
+        self.values.append(out[0].numpy().reshape(()).copy())
+        self.policies.append(out[1].numpy().reshape(65).copy())
+        return out
+
+
+def reach_position(game_id, n_moves, seed=SEED):
+    """a reference Game advanced n_moves by the build RNG (same stream as the env fixtures)."""
+    game = M.Game()
+    for step in range(n_moves):
+        s = env_state(game.environment)
+        a = R.playout_action(seed, game_id, step, s[5])
+        game.apply(M.Action(a, game.to_play()))
+    return game
+
+
+def run_reference_search(game, net, S, noise_seed, use_noise=True, known_bounds=(-1, 1),
+                         discount=1.0):
+    """one reference search (main.py:75-88 composition) with instrumentation; returns a dict."""
+    M.config.num_simulations = S
+    M.config.known_bounds = known_bounds
+    M.config.discount = discount
+    paths, cur = [], []
+    orig_select = M.select_child
+
+    def rec_select(node, mm):
+        a, child = orig_select(node, mm)
+        cur.append(a)
+        return a, child
+
+    orig_backprop = M.backpropagate
+
+    def rec_backprop(search_path, value, player, discount, mm):
+        paths.append(list(cur))
+        cur.clear()
+        return orig_backprop(search_path, value, player, discount, mm)
+
+    M.select_child, M.backpropagate = rec_select, rec_backprop
+    try:
+        root = M.Node(0, game.to_play())
+        image = torch.from_numpy(game.make_image(game.environment.steps))
+        out0 = net.initial_inference(image)
+        legal = sorted(game.legal_actions(), key=lambda a: a.index)  # H3: sorted legal list
+        M.expand_node(root, legal, out0)
+        noise = np.zeros(65, np.float64)
+        if use_noise:
+            np.random.seed(noise_seed)
+            st = np.random.get_state()
+            M.add_exploration_noise(root)
+            rs = np.random.RandomState()
+            rs.set_state(st)
+            drawn = rs.dirichlet([M.config.root_dirichlet_alpha] * len(legal))
+            for a, n in zip(legal, drawn):
+                noise[a.index] = n
+        M.run_mcts(root, game.action_history, net)
+    finally:
+        M.select_child, M.backpropagate = orig_select, orig_backprop
+    visits = np.full(65, -1, np.int32)
+    wsum = np.zeros(65, np.float32)
+    prior = np.zeros(65, np.float64)
+    for a, c in root.children.items():
+        visits[a] = c.visit_count
+        wsum[a] = float(c.value_sum) if c.visit_count else 0.0
+        prior[a] = c.prior
+    s = env_state(game.environment)
+    # select_action (main.py:128-140): greedy = first max in children (= sorted legal) order;
+    # sampled = np.random.choice with the uniform u replayed from the same generator state.
+    greedy = M.softmax_sample([(c.visit_count, a) for a, c in root.children.items()], 0)
+    np.random.seed(noise_seed + 77)
+    st = np.random.get_state()
+    sampled = M.softmax_sample([(c.visit_count, a) for a, c in root.children.items()], 1)
+    rs = np.random.RandomState()
+    rs.set_state(st)
+    u = rs.random_sample()
+    game2 = M.Game()
+    game2.store_search_statistics(root)
+    return dict(white=s[0], black=s[1], to_play=s[2], steps=s[3], legal=s[5], pass_flag=s[6],
+                root_value0=np.float32(out0[0].numpy().reshape(())), root_policy=out0[1].numpy().reshape(65),
+                noise=noise, use_noise=int(use_noise), S=S, paths=paths, visits=visits, wsum=wsum,
+                prior=prior, root_n=root.visit_count,
+                root_value=np.float32(root.value().numpy().reshape(())) if root.visit_count else np.float32(0),
+                greedy=int(greedy), sampled=int(sampled), u=u,
+                child_visits=np.array(game2.child_visits[0], np.float64),
+                image=image.numpy().copy())
+
+
+def gen_mcts():
+    cases = []
+    meta = []
+    # (mode, S, game_id, n_moves, noise, bounds, discount)
+    plan = []
+    gid = 0
+    for S in (50, 60, 100):
+        for n_moves in (0, 1, 7, 20, 33, 45, 58):
+            plan.append(("hash", S, gid, n_moves, True, (-1, 1), 1.0)); gid += 1
+    for mode in ("uniform", "sat", "const"):
+        for n_moves in (0, 12, 40):
+            plan.append((mode, 60, gid, n_moves, mode != "uniform", (-1, 1), 1.0)); gid += 1
+    plan.append(("uniform", 200, gid, 0, False, (-1, 1), 1.0)); gid += 1   # deep pure tie-break tree
+    plan.append(("hash", 60, gid, 5, False, (-1, 1), 1.0)); gid += 1       # no noise
+    plan.append(("hash", 60, gid, 9, True, None, 1.0)); gid += 1           # known_bounds = None
+    plan.append(("sat", 60, gid, 9, True, None, 1.0)); gid += 1
+    plan.append(("hash", 60, gid, 11, True, (-1, 1), 0.5)); gid += 1       # discount knob
+    plan.append(("hash", 60, gid, 11, True, None, 0.997)); gid += 1
+    plan.append(("hash", 60, gid, 11, True, (-0.5, 0.5), 1.0)); gid += 1   # bounds that DO get replaced
+    # a pass-only root: scan the env fixture stream for a game whose position has no legal move
+    for g in range(4096):
+        game = M.Game()
+        found = None
+        for step in range(59):
+            s = env_state(game.environment)
+            if s[6]:
+                found = step
+                break
+            game.apply(M.Action(R.playout_action(SEED, g, step, s[5]), game.to_play()))
+        if found is not None and found < 57:
+            plan.append(("hash", 60, g, found, True, (-1, 1), 1.0))
+            break
+    for (mode, S, g, n_moves, noise, bounds, disc) in plan:
+        game = reach_position(g, n_moves)
+        net = HashNetwork(mode)
+        res = run_reference_search(game, net, S, 1000 + g, noise, bounds, disc)
+        res.update(mode=R.MODES[mode], kind=0, bounds_none=int(bounds is None),
+                   bound_lo=(bounds[0] if bounds else 0.0), bound_hi=(bounds[1] if bounds else 0.0),
+                   discount=disc, net_values=np.zeros(0, np.float32), net_policies=np.zeros((0, 65), np.float32))
+        cases.append(res)
+        print("mcts hash case", mode, S, g, n_moves, "maxdepth", max(len(p) for p in res["paths"]),
+              "visits", res["visits"][res["visits"] >= 0].tolist())
+    # real-network searches: outputs recorded, replayed in the tests (H6)
+    torch.manual_seed(1261)
+    real = M.Network()
+    real.eval()
+    for i, (S, n_moves) in enumerate([(50, 0), (60, 3), (60, 18), (100, 30), (60, 44), (60, 57)]):
+        game = reach_position(2000 + i, n_moves)
+        net = RecordingNetwork(real)
+        res = run_reference_search(game, net, S, 5000 + i, True)
+        res.update(mode=-1, kind=1, bounds_none=0, bound_lo=-1.0, bound_hi=1.0, discount=1.0,
+                   net_values=np.array(net.values, np.float32), net_policies=np.array(net.policies, np.float32))
+        cases.append(res)
+        print("mcts real case", S, n_moves, "maxdepth", max(len(p) for p in res["paths"]),
+              "visits", res["visits"][res["visits"] >= 0].tolist())
+    M.config.num_simulations, M.config.known_bounds, M.config.discount = 60, (-1, 1), 1.0
+    out = {}
+    scal = ["white", "black", "to_play", "steps", "legal", "pass_flag", "root_value0", "use_noise", "S",
+            "root_n", "root_value", "greedy", "sampled", "u", "mode", "kind", "bounds_none", "bound_lo",
+            "bound_hi", "discount"]
+    dt = dict(white=np.uint64, black=np.uint64, legal=np.uint64, to_play=np.int8, root_value0=np.float32,
+              root_value=np.float32, u=np.float64, bound_lo=np.float64, bound_hi=np.float64,
+              discount=np.float64)
+    for k in scal:
+        out[k] = np.array([c[k] for c in cases], dt.get(k, np.int32))
+    for k in ("root_policy", "noise", "visits", "wsum", "prior", "child_visits", "image"):
+        out[k] = np.stack([c[k] for c in cases])
+    # ragged: per-sim paths; per-case net outputs
+    path_flat, path_off, sim_off = [], [0], [0]
+    for c in cases:
+        for p in c["paths"]:
+            path_flat.extend(p)
+            path_off.append(len(path_flat))
+        sim_off.append(len(path_off) - 1)
+    out["path_actions"] = np.array(path_flat, np.uint8)
+    out["path_off"] = np.array(path_off, np.int64)
+    out["sim_off"] = np.array(sim_off, np.int64)
+    out["net_values"] = np.concatenate([c["net_values"] for c in cases])
+    out["net_policies"] = np.concatenate([c["net_policies"] for c in cases])
+    out["net_off"] = np.cumsum([0] + [len(c["net_values"]) for c in cases]).astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "mcts_traces.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# feature traces: make_image / Action.encode / make_target inputs
+# ------------------------------------------------------------------------------------------------
+def gen_features():
+    out = {}
+    enc = []
+    for idx in (0, 7, 19, 63, 64):
+        for pl in (M.Player.WHITE, M.Player.BLACK):
+            enc.append((idx, pl.value, M.Action(idx, pl).encode().astype(np.uint8)))
+    out["enc_index"] = np.array([e[0] for e in enc], np.int32)
+    out["enc_player"] = np.array([e[1] for e in enc], np.int8)
+    out["enc_planes"] = np.stack([e[2] for e in enc])
+    # make_image along whole games (incl. ones with passes): store states + images at many indices
+    gids = [0, 1, 2, 3]
+    acts = np.load(os.path.join(HERE, "env_traces.npz"))["dig_actions"]
+    with_pass = [int(g) for g in np.nonzero((acts[:, :50] == 64).any(1))[0][:4]]
+    gids += with_pass
+    imgs, meta, hw, hb = [], [], [], []
+    for g in gids:
+        game = reach_position(g, 60)
+        W = np.zeros(61, np.uint64); B = np.zeros(61, np.uint64)
+        for t, obs in enumerate(game.state_history):
+            w = b = 0
+            for i in range(64):
+                if obs[0].reshape(-1)[i]:
+                    w |= 1 << i
+                if obs[1].reshape(-1)[i]:
+                    b |= 1 << i
+            W[t], B[t] = w, b
+        hw.append(W); hb.append(B)
+        for idx in list(range(0, 8)) + [20, 35, 59, 60]:
+            imgs.append(game.make_image(idx).astype(np.uint8))
+            meta.append((len(hw) - 1, idx))
+    out["img_game"] = np.array([m[0] for m in meta], np.int32)
+    out["img_index"] = np.array([m[1] for m in meta], np.int32)
+    out["img"] = np.stack(imgs)
+    out["hist_white"] = np.stack(hw)
+    out["hist_black"] = np.stack(hb)
+    out["game_ids"] = np.array(gids, np.int32)
+    np.savez_compressed(os.path.join(HERE, "features.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole self-play games (main.play_game) with HashNet: the end-to-end composition
+# ------------------------------------------------------------------------------------------------
+def gen_game():
+    """reference main.play_game (main.py:69-92) on HashNet, with np.random draws recorded.
+
+    The only harness intervention: Game.legal_actions returns the env's list sorted by index (H3).
+    """
+    orig_legal = M.Game.legal_actions
+    M.Game.legal_actions = lambda self: sorted(self.environment.legal_actions, key=lambda a: a.index)
+    orig_dir, orig_choice = np.random.dirichlet, np.random.choice
+    out = {}
+    try:
+        recs = []
+        for gi, (S, seed) in enumerate([(16, 11), (16, 12), (30, 13)]):
+            M.config.num_simulations = S
+            np.random.seed(seed)
+            noises, us = [], []
+
+            def rec_dirichlet(alpha, *a, **k):
+                d = orig_dir(alpha, *a, **k)
+                noises.append(np.array(d))
+                return d
+
+            def rec_choice(actions, p=None):
+                st = np.random.get_state()
+                r = orig_choice(actions, p=p)
+                rs = np.random.RandomState()
+                rs.set_state(st)
+                us.append(rs.random_sample())
+                return r
+
+            np.random.dirichlet, np.random.choice = rec_dirichlet, rec_choice
+            game = M.play_game(HashNetwork("hash"))
+            np.random.dirichlet, np.random.choice = orig_dir, orig_choice
+            n = len(game.action_history)
+            # noise by action index: replay legal sets from the stored states
+            g2 = M.Game()
+            noise = np.zeros((n, 65), np.float64)
+            for t in range(n):
+                legal = sorted(a.index for a in g2.environment.legal_actions)
+                noise[t, legal] = noises[t]
+                g2.apply(M.Action(game.action_history[t].index, g2.to_play()))
+            u = np.zeros(n, np.float64)
+            u[:len(us)] = us  # moves >= 20 are greedy and draw nothing
+            recs.append(dict(S=S, actions=np.array([a.index for a in game.action_history], np.uint8),
+                             rewards=np.array(game.rewards, np.int8), noise=noise, u=u,
+                             child_visits=np.array(game.child_visits, np.float64),
+                             root_values=np.array([float(v) for v in game.root_values], np.float32),
+                             done=int(game.terminal())))
+            print("game", gi, "S", S, "moves", n, "done", game.terminal(), "last reward", game.rewards[-1])
+        for k in recs[0]:
+            if k in ("S", "done"):
+                out[k] = np.array([r[k] for r in recs], np.int32)
+            else:
+                for i, r in enumerate(recs):
+                    out["%s_%d" % (k, i)] = r[k]
+    finally:
+        M.Game.legal_actions = orig_legal
+        np.random.dirichlet, np.random.choice = orig_dir, orig_choice
+        M.config.num_simulations = 60
+    np.savez_compressed(os.path.join(HERE, "selfplay_games.npz"), **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("env", "all"):
+        gen_env()
+    if what in ("mcts", "all"):
+        gen_mcts()
+    if what in ("features", "all"):
+        gen_features()
+    if what in ("game", "all"):
+        gen_game()
