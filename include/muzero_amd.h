@@ -1,0 +1,207 @@
+/*
+ * muzero_amd.h -- C ABI of libmuzero_amd.so: batched reversi env + batched MCTS for MI355X (gfx950).
+ *
+ * The reference (ZiyuanMa/MuZero) is pure Python and has no FFI; the boundary this library sits
+ * behind is the set of Python callables main.py's self-play loop uses.  Every entry
+ * point below names the reference code it replaces (file:line in /root/reference).  The Python
+ * binding (muzero_amd/_lib.py, ctypes) and the reference-shaped shims (muzero_amd/compat.py) sit
+ * above this header; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); the caller owns all
+ *     memory; the library never allocates or frees device memory (safe under hipGraph capture);
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); calls are
+ *     asynchronous on it, except mz_pool_init which also performs one small synchronous H2D copy;
+ *   - return 0 on success, <0 on error (MZ_E_*), never throws; mz_last_error() gives the text;
+ *   - per-game problems (illegal action, finished game) are reported in status bytes, not errors;
+ *   - thread-compatible: no hidden global state besides the thread-local error string.
+ *
+ * Data model
+ *   board    : two uint64 bitboards per game, bit i <=> Action.index i = row*8+col
+ *              (reversi.py:19-30); `white` = Player.WHITE(+1) discs, `black` = Player.BLACK(-1)
+ *   to_play  : int8, +1 WHITE / -1 BLACK (reversi.py:14-16); BLACK moves first (reversi.py:54)
+ *   steps    : uint8, Environment.steps (passes count, reversi.py:133)
+ *   done     : uint8, Environment.done (set only by a placing move made at steps==60, :170-172)
+ *   legal    : uint64 mask of legal placements = Environment.legal_actions; 0 <=> [Action(64)]
+ *   action   : uint8 in [0,64], 64 = pass
+ */
+#ifndef MUZERO_AMD_H
+#define MUZERO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZ_ACTIONS 65       /* config.py:10 action_space_size */
+#define MZ_HIDDEN_ELEMS 512 /* network.py:66-69 hidden state (8,8,8) */
+
+#define MZ_OK 0
+#define MZ_E_ARG (-1)  /* null pointer / bad size / bad enum */
+#define MZ_E_HIP (-2)  /* a HIP runtime call or launch failed */
+
+/* per-game status bytes written by mz_env_step */
+#define MZ_ST_OK 0
+#define MZ_ST_ILLEGAL 1 /* reference would assert / raise: reversi.py:26,143-144,164-165 */
+#define MZ_ST_DONE 2    /* game already finished; state left untouched (batch convention) */
+
+/* element type of hidden states / network input buffers */
+#define MZ_F32 0
+#define MZ_BF16 1
+#define MZ_F16 2
+
+const char *mz_last_error(void);
+int mz_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Environment (reversi.py:39-205)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Environment.__init__ (reversi.py:41-58) for n games. */
+int mz_env_reset(uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *steps, uint8_t *done,
+                 uint64_t *legal, int64_t n, void *stream);
+
+/* Environment.update_legal_actions / check_position / check_direction (reversi.py:81-126) for the
+ * side `to_play` on arbitrary positions: Kogge-Stone directional fills on bitboards. */
+int mz_env_legal_mask(const uint64_t *black, const uint64_t *white, const int8_t *to_play,
+                      uint64_t *legal, int64_t n, void *stream);
+
+/* Environment.step (reversi.py:130-180) for n games in place: flips, pass, step counter, terminal
+ * rule and check_win (:197-205), player switch and legal refresh -- including the quirks: passes
+ * consume the 60-step budget and are accepted without a legality check; after the terminal move
+ * to_play and legal are left stale.  reward: int8 (+1/0/-1), status: MZ_ST_*. */
+int mz_env_step(uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *steps, uint8_t *done,
+                uint64_t *legal, const uint8_t *action, int8_t *reward, uint8_t *status, int64_t n,
+                void *stream);
+
+/* BASELINE.json config 2: games [game0, game0+n) played from the opening for n_steps steps with
+ * uniformly random legal moves (counter-based RNG keyed (seed, game, step); k-th legal bit in
+ * ascending index), state held in registers for the whole game.  voluntary != 0 also
+ * plays a pass with probability 1/8 although moves exist (reversi.py:135-139 accepts that).
+ * Outputs: final state; digest (nullable) = running 64-bit digest of all n_steps+1 states;
+ * actions (nullable) = n x n_steps action log; last_reward (nullable). */
+int mz_env_random_playout(uint64_t seed, uint64_t game0, int64_t n, int32_t n_steps, int32_t voluntary,
+                          uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *steps, uint8_t *done,
+                          uint64_t *legal, uint64_t *digest, uint8_t *actions, int8_t *last_reward,
+                          void *stream);
+
+/* the same RNG, one step at a time on HBM-resident state: action[i] = random legal move of game
+ * game0+i at step `step` (64 if none).  Used with mz_env_step by the HBM-resident bench mode. */
+int mz_env_random_action(uint64_t seed, uint64_t game0, int32_t step, const uint64_t *legal,
+                         uint8_t *action, int64_t n, void *stream);
+
+/* Action.encode (reversi.py:32-36) for n actions -> out (n,2,8,8) of dtype: layer 0 for WHITE else
+ * 1; rows r and c of that layer set for index = r*8+c (numpy fancy-index behaviour of the
+ * reference), whole layer for pass. */
+int mz_action_encode(const uint8_t *action, const int8_t *player, void *out, int32_t dtype, int64_t n,
+                     void *stream);
+
+/* Game.make_image (reversi.py:301-312) + Environment.observe (:182-186) for n games.
+ * hist_white/hist_black: observation history, step-major [t * hist_stride + game], t = 0..60.
+ * state_index: per-game (nullable) else the uniform `state_index_all`.  out: (n,9,8,8) of dtype. */
+int mz_make_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride,
+                  const int32_t *state_index, int32_t state_index_all, void *out, int32_t dtype, int64_t n,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Tree search (main.py:99-196, 275-285; reversi.py:234-251 Node; utilities.py:114-129 MinMaxStats)
+ * ---------------------------------------------------------------------------------------- */
+
+/* config.py knobs the search reads */
+typedef struct mz_search_cfg {
+    double pb_c_base;   /* config.py:22 */
+    double pb_c_init;   /* config.py:23 */
+    double discount;    /* config.py:15 */
+    double noise_frac;  /* config.py:19 root_exploration_fraction */
+    double bound_lo;    /* config.py:29 known_bounds[0] */
+    double bound_hi;    /* config.py:29 known_bounds[1] */
+    int32_t bounds_none; /* known_bounds = None */
+    int32_t tie_lowest;  /* 0 = reference: max over (score, action) tuples, ties -> HIGHEST index
+                            (main.py:145-147); 1 = lowest index (BASELINE.json wording) */
+} mz_search_cfg;
+
+/* Node pool for n_trees independent searches of at most max_nodes-1 simulations each, laid out by
+ * the library inside ONE caller-owned device buffer of total_bytes (256-B aligned base):
+ *   stats  [tree][node][65] x 16 B  { uint32 n_child; float W; double P }   (Node, reversi.py:236-243)
+ *            n_child = visit_count | (expanded-node id + 1) << 16 ; 0xFFFFFFFF = not a child
+ *            W = value_sum (fp32, accumulated in simulation order); P = prior (float64)
+ *   hidden [tree][node][512] x elem  Node.hidden_state of expanded nodes
+ *   meta   [tree] x 64 B            root N/W/player, MinMaxStats, node count, path length, leaf info
+ *   path   [tree][max_nodes] x 4 B  search_path of the current simulation {uint16 node; uint8 action}
+ *   pbc    [max_nodes+1] x 16 B     host-computed {log((N+base+1)/base)+init, sqrt(N)} (glibc, as
+ *                                   CPython's math.log/math.sqrt: main.py:154-156)
+ */
+typedef struct mz_pool_layout {
+    int64_t total_bytes;
+    int64_t off_stats, off_hidden, off_meta, off_path, off_pbc;
+    int32_t n_trees, max_nodes, hidden_dtype, hidden_elem_bytes;
+} mz_pool_layout;
+
+/* tree meta record (64 B); offsets are part of the ABI so tests can inspect trees */
+typedef struct mz_tree_meta {
+    int32_t n_nodes;     /* expanded nodes (root = node 0) */
+    int32_t root_n;      /* root.visit_count */
+    float root_w;        /* root.value_sum */
+    int32_t root_player; /* +1 / -1 */
+    double mm_min;       /* MinMaxStats.minimum (value; fp32-exact when flagged tensor) */
+    double mm_max;       /* MinMaxStats.maximum */
+    int32_t mm_flags;    /* bit0: minimum is an fp32 tensor, bit1: maximum is (else Python float) */
+    int32_t path_len;    /* edges of the current simulation's path */
+    int32_t leaf_player; /* player of the leaf of the current simulation */
+    int32_t error;       /* bit0: pool full; bit1: select without root */
+    int32_t leaf_parent; /* expanded-node id whose hidden state feeds recurrent_inference */
+    int32_t leaf_action; /* history[-1].index */
+    int32_t pad[2];
+} mz_tree_meta;
+
+/* host-only: compute the layout (no device access). max_nodes in [2, 65534]. */
+int mz_pool_layout_compute(int32_t n_trees, int32_t max_nodes, int32_t hidden_dtype, mz_pool_layout *out);
+
+/* upload the pb_c table for cfg and clear meta.  Re-run when cfg.pb_c_* change. */
+int mz_pool_init(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg, void *stream);
+
+/* play_game's root set-up (main.py:75-83): root = Node(0, to_play); expand_node(root,
+ * legal_actions, initial_inference output) over the legal placements in ascending index (pass iff
+ * legal == 0); add_exploration_noise with caller-supplied Dirichlet noise indexed by ACTION
+ * (noise nullable = none); MinMaxStats(known_bounds) (main.py:100).
+ * policy: (n,65) f32 rows; hidden: (n,512) of the pool's dtype; noise: (n,65) f64. */
+int mz_mcts_root_init(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
+                      const int8_t *to_play, const uint64_t *legal, const float *policy, const double *noise,
+                      const void *hidden, int32_t n_trees, void *stream);
+
+/* one simulation's descent for every tree (run_mcts main.py:103-118 = select_child :144-148 +
+ * ucb_score :153-160 per level), one wavefront per tree.  Writes the path, and the network input
+ * for recurrent_inference: net_in (n,10,8,8) of the pool's dtype = parent hidden state (8 planes)
+ * followed by Action.encode of the last action tagged with the CHILD's player (main.py:110). */
+int mz_mcts_select(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg, void *net_in,
+                   int32_t n_trees, void *stream);
+
+/* expand_node over all 65 actions (main.py:123,165-175) + backpropagate (:180-186) along the path
+ * stored by mz_mcts_select.  value: (n) f32, policy: (n,65) f32, hidden: (n,512) pool dtype. */
+int mz_mcts_expand_backup(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
+                          const float *value, const float *policy, const void *hidden, int32_t n_trees,
+                          void *stream);
+
+/* fused: mz_mcts_expand_backup of simulation s followed by mz_mcts_select of simulation s+1 in one
+ * launch (the tree's records are still in registers / L2). */
+int mz_mcts_backup_select(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
+                          const float *value, const float *policy, const void *hidden, void *net_in,
+                          int32_t n_trees, void *stream);
+
+/* root statistics after the search: visits (n,65) i32 (-1 = not a child) as consumed by
+ * Game.store_search_statistics (reversi.py:292-299) and select_action (main.py:128-140);
+ * root_value (n) f32 = root.value(); wsum (n,65) f32 / prior (n,65) f64 nullable (tests). */
+int mz_mcts_root_stats(const void *pool, const mz_pool_layout *layout, int32_t *visits, float *root_value,
+                       float *wsum, double *prior, int32_t n_trees, void *stream);
+
+/* select_action + softmax_sample (main.py:128-140, 275-285): temperature 1 while num_moves < 20
+ * (np.random.choice == cdf search with the caller's uniform u), else first maximum in ascending
+ * action order.  num_moves: per-game (nullable) else num_moves_all. */
+int mz_select_action(const int32_t *visits, const int32_t *num_moves, int32_t num_moves_all, const double *u,
+                     uint8_t *action, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUZERO_AMD_H */

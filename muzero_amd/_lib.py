@@ -1,0 +1,93 @@
+"""ctypes binding of libmuzero_amd.so (include/muzero_amd.h).
+
+There is no CPU fallback: importing this module without the built HIP library raises, and every
+wrapper raises on a non-zero return code with the library's error text.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmuzero_amd.so")
+
+MZ_F32, MZ_BF16, MZ_F16 = 0, 1, 2
+ST_OK, ST_ILLEGAL, ST_DONE = 0, 1, 2
+
+
+class MzError(RuntimeError):
+    pass
+
+
+class SearchCfg(C.Structure):
+    """mz_search_cfg -- the config.py knobs the search reads (config.py:15,19,22,23,29)."""
+    _fields_ = [("pb_c_base", C.c_double), ("pb_c_init", C.c_double), ("discount", C.c_double),
+                ("noise_frac", C.c_double), ("bound_lo", C.c_double), ("bound_hi", C.c_double),
+                ("bounds_none", C.c_int32), ("tie_lowest", C.c_int32)]
+
+
+class PoolLayout(C.Structure):
+    """mz_pool_layout"""
+    _fields_ = [("total_bytes", C.c_int64), ("off_stats", C.c_int64), ("off_hidden", C.c_int64),
+                ("off_meta", C.c_int64), ("off_path", C.c_int64), ("off_pbc", C.c_int64),
+                ("n_trees", C.c_int32), ("max_nodes", C.c_int32), ("hidden_dtype", C.c_int32),
+                ("hidden_elem_bytes", C.c_int32)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "muzero_amd: %s is missing. Build it with `make -C muzero_amd/csrc` (or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_p, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+_LP, _CP = C.POINTER(PoolLayout), C.POINTER(SearchCfg)
+
+# name -> argtypes; every symbol include/muzero_amd.h declares (tests check the export list)
+SIGNATURES = {
+    "mz_env_reset": [_p] * 6 + [_i64, _p],
+    "mz_env_legal_mask": [_p] * 4 + [_i64, _p],
+    "mz_env_step": [_p] * 9 + [_i64, _p],
+    "mz_env_random_playout": [_u64, _u64, _i64, _i32, _i32] + [_p] * 9 + [_p],
+    "mz_env_random_action": [_u64, _u64, _i32, _p, _p, _i64, _p],
+    "mz_action_encode": [_p, _p, _p, _i32, _i64, _p],
+    "mz_make_image": [_p, _p, _i64, _p, _i32, _p, _i32, _i64, _p],
+    "mz_pool_layout_compute": [_i32, _i32, _i32, _LP],
+    "mz_pool_init": [_p, _LP, _CP, _p],
+    "mz_mcts_root_init": [_p, _LP, _CP, _p, _p, _p, _p, _p, _i32, _p],
+    "mz_mcts_select": [_p, _LP, _CP, _p, _i32, _p],
+    "mz_mcts_expand_backup": [_p, _LP, _CP, _p, _p, _p, _i32, _p],
+    "mz_mcts_backup_select": [_p, _LP, _CP, _p, _p, _p, _p, _i32, _p],
+    "mz_mcts_root_stats": [_p, _LP, _p, _p, _p, _p, _i32, _p],
+    "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
+}
+for _name, _args in SIGNATURES.items():
+    _f = getattr(lib, _name)
+    _f.argtypes = _args
+    _f.restype = C.c_int
+lib.mz_last_error.restype = C.c_char_p
+lib.mz_last_error.argtypes = []
+lib.mz_version.restype = C.c_int
+lib.mz_version.argtypes = []
+EXPORTS = sorted(list(SIGNATURES) + ["mz_last_error", "mz_version"])
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MzError("%s failed (%d): %s" % (name, rc, lib.mz_last_error().decode()))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t):
+    """device pointer of a torch tensor (None -> NULL); refuses host tensors loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MzError("muzero_amd kernels need device tensors; got a %s tensor (no CPU fallback)" % t.device)
+    if not t.is_contiguous():
+        raise MzError("muzero_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())

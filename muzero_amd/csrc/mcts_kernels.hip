@@ -1,0 +1,510 @@
+// mcts_kernels.hip -- batched MuZero tree search for gfx950: struct-of-arrays node pool in HBM,
+// ONE WAVEFRONT PER GAME TREE.
+//
+// Replaces main.py:99-196 (run_mcts, select_child, ucb_score, expand_node, backpropagate,
+// add_exploration_noise), main.py:128-140/275-285 (select_action, softmax_sample),
+// reversi.py:234-251 (Node) and utilities.py:114-129 (MinMaxStats).
+//
+// Mapping.  A node's 65 children are one 16-byte record each; lane l of the tree's wave owns child
+// l (one coalesced 1 KiB load per tree level), child 64 (pass) is loaded wave-uniformly and scored
+// redundantly by every lane.  A child's statistics are consumed by exactly one lane, so they stay
+// in VGPRs -- an LDS round trip would be pure overhead -- and the argmax is wavefront ballots and
+// shuffle reductions.  No LDS is used by any kernel in this file.
+//
+// Numerics.  The reference mixes Python floats (double) and fp32 tensors:
+//   prior, pb_c, prior_score        double
+//   child.value() = W/N             fp32 tensor when N > 0, Python int 0 when N == 0
+//   normalize / prior_score + value fp32 if any operand is a tensor, else double
+//   score comparisons               fp32 if either side is a tensor, else double
+// `Mx` models that.  Builtin max() over (score, action) tuples is a sequential scan that replaces
+// on "greater"; mixed comparisons make that order non-transitive, so select_argmax() below
+// computes the *exact* result of the sequential scan with wave-parallel primitives (derivation in
+// DESIGN.md, "select_child as a parallel scan").  log/sqrt of the pb_c term come from a host table
+// (glibc, as CPython's math.log/math.sqrt) so no device libm rounding enters the score.
+// This file must be compiled with -ffp-contract=off.
+#include <math.h>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+struct alignas(16) ChildRec {
+    uint32_t nc;  // visit_count | (expanded id + 1) << 16 ; NOT_CHILD = not in parent's children dict
+    float w;      // value_sum
+    double p;     // prior
+};
+constexpr uint32_t NOT_CHILD = 0xFFFFFFFFu;
+struct alignas(4) PathRec { uint16_t node; uint8_t action; uint8_t pad; };
+struct alignas(16) PbcRec { double a, s; };
+
+struct Pool {
+    ChildRec *stats;
+    char *hidden;
+    mz_tree_meta *meta;
+    PathRec *path;
+    const PbcRec *pbc;
+    int max_nodes, hidden_elem_bytes;
+    uint32_t one16x2;  // two packed 1.0 values of the 16-bit hidden dtype
+};
+
+Pool make_pool(const void *base, const mz_pool_layout *L) {
+    char *b = (char *)base;
+    Pool p;
+    p.stats = (ChildRec *)(b + L->off_stats);
+    p.hidden = b + L->off_hidden;
+    p.meta = (mz_tree_meta *)(b + L->off_meta);
+    p.path = (PathRec *)(b + L->off_path);
+    p.pbc = (const PbcRec *)(b + L->off_pbc);
+    p.max_nodes = L->max_nodes;
+    p.hidden_elem_bytes = L->hidden_elem_bytes;
+    p.one16x2 = L->hidden_dtype == MZ_BF16 ? 0x3F803F80u : 0x3C003C00u;
+    return p;
+}
+
+// ---- mixed Python-float / fp32-tensor numbers ---------------------------------------------------
+struct Mx { double d; bool t; };  // t: value is an fp32 tensor (d holds it exactly)
+__device__ __forceinline__ Mx mx_py(double d) { return Mx{d, false}; }
+__device__ __forceinline__ Mx mx_t(float f) { return Mx{(double)f, true}; }
+__device__ __forceinline__ float mx_f(Mx a) { return (float)a.d; }
+__device__ __forceinline__ Mx mx_sub(Mx a, Mx b) { return (a.t || b.t) ? mx_t(mx_f(a) - mx_f(b)) : mx_py(a.d - b.d); }
+__device__ __forceinline__ Mx mx_add(Mx a, Mx b) { return (a.t || b.t) ? mx_t(mx_f(a) + mx_f(b)) : mx_py(a.d + b.d); }
+__device__ __forceinline__ Mx mx_div(Mx a, Mx b) { return (a.t || b.t) ? mx_t(mx_f(a) / mx_f(b)) : mx_py(a.d / b.d); }
+__device__ __forceinline__ bool mx_gt(Mx a, Mx b) { return (a.t || b.t) ? (mx_f(a) > mx_f(b)) : (a.d > b.d); }
+__device__ __forceinline__ bool mx_lt(Mx a, Mx b) { return (a.t || b.t) ? (mx_f(a) < mx_f(b)) : (a.d < b.d); }
+
+struct MinMax { Mx lo, hi; };
+// MinMaxStats.normalize utilities.py:125-129
+__device__ __forceinline__ Mx mm_normalize(const MinMax &mm, Mx v) {
+    if (mx_gt(mm.hi, mm.lo)) return mx_div(mx_sub(v, mm.lo), mx_sub(mm.hi, mm.lo));
+    return v;
+}
+__device__ __forceinline__ MinMax load_minmax(const mz_tree_meta *m) {
+    MinMax mm;
+    const int f = m->mm_flags;
+    mm.lo = Mx{m->mm_min, (f & 1) != 0};
+    mm.hi = Mx{m->mm_max, (f & 2) != 0};
+    return mm;
+}
+
+// ---- wave primitives ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int hi_bit(uint64_t m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ int lo_bit(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
+__device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// ucb_score main.py:153-160 for one child record
+__device__ __forceinline__ Mx ucb_score(const ChildRec &r, const PbcRec &pb, const MinMax &mm) {
+    const uint32_t n = r.nc & 0xFFFFu;
+    const double pb_c = pb.a * (pb.s / (double)(n + 1u));
+    const double prior_score = pb_c * r.p;
+    const Mx value = n == 0 ? mx_py(0.0) : mx_t(r.w / (float)n);  // Node.value() reversi.py:248-251
+    return mx_add(mx_py(prior_score), mm_normalize(mm, value));
+}
+
+// select_child main.py:144-148: exact result of builtin max over (score, action) tuples scanned in
+// ascending action order, computed wave-parallel.  Lane l holds child l (valid/s); child 64 is
+// wave-uniform (valid64/s64).  key = fp32(score) totally orders items of different kind; items of
+// Python-float kind (D) are ordered among themselves in double; a tensor-kind item (F) compares
+// equal to every item with the same key.  See DESIGN.md for the proof of equivalence.
+__device__ __forceinline__ int select_argmax(bool valid, Mx s, bool valid64, Mx s64, int lane, bool tie_lowest) {
+    const float key = valid ? mx_f(s) : -INFINITY;
+    const float key64 = valid64 ? mx_f(s64) : -INFINITY;
+    const float K = fmaxf(wave_max_f32(key), key64);
+    const bool at = valid && key == K, at64 = valid64 && key64 == K;
+    const uint64_t mF = __ballot(at && s.t), mD = __ballot(at && !s.t);
+    const bool F64 = at64 && s64.t, D64 = at64 && !s64.t;
+    if (!tie_lowest) {
+        // j = last tensor-kind item at key K: it replaces whatever precedes it; after it only
+        // D items remain, which are maximised in double with ties to the later index.
+        const int j = F64 ? 64 : (mF ? hi_bit(mF) : -1);
+        if (j == 64) return 64;
+        const uint64_t below = j < 0 ? 0ULL : (j == 63 ? ~0ULL : ((2ULL << j) - 1ULL));
+        const uint64_t cand = mD & ~below;
+        const int ncand = __popcll(cand) + (D64 ? 1 : 0);
+        if (ncand == 0) return j;
+        if (ncand == 1) return D64 ? 64 : hi_bit(cand);
+        const bool mine = (cand >> lane) & 1ULL;
+        double dmax = wave_max_f64(mine ? s.d : -INFINITY);
+        if (D64) dmax = fmax(dmax, s64.d);
+        if (D64 && s64.d == dmax) return 64;
+        return hi_bit(__ballot(mine && s.d == dmax));
+    }
+    // non-default: replace only on strictly greater -> the first item wins ties
+    const uint64_t mall = mF | mD;
+    if (!mall) return 64;
+    const int first = lo_bit(mall);
+    if ((mF >> first) & 1ULL) return first;  // a tensor-kind first item is never exceeded at key K
+    const bool mine = (mD >> lane) & 1ULL;
+    double dmax = wave_max_f64(mine ? s.d : -INFINITY);
+    if (D64) dmax = fmax(dmax, s64.d);
+    const uint64_t me = __ballot(mine && s.d == dmax);
+    return me ? lo_bit(me) : 64;
+}
+
+// Action.encode rows (reversi.py:32-36; see env_kernels.hip)
+__device__ __forceinline__ unsigned encode_rows(int a) { return a >= 64 ? 0xFFu : ((1u << (a >> 3)) | (1u << (a & 7))); }
+
+// copy one hidden state (512 elements) with the whole wave, 16 B per lane per step
+__device__ __forceinline__ void copy_hidden(char *dst, const char *src, int elem_bytes, int lane) {
+    const uint4 *s = (const uint4 *)src;
+    uint4 *d = (uint4 *)dst;
+    const int n16 = (MZ_HIDDEN_ELEMS * elem_bytes) >> 4;  // 128 (f32) or 64 (16-bit)
+    for (int i = lane; i < n16; i += 64) d[i] = s[i];
+}
+
+// expand_node main.py:165-175: priors over the masked actions, policy_sum sequential in double in
+// ascending action order (H3).  Writes the 65 child records of `node`.
+template <bool ALL>
+__device__ __forceinline__ void write_children(const Pool &P, int64_t node_row, const float *policy, uint64_t mask, bool pass_ok,
+                                               const double *noise, double frac, int lane) {
+    const float p = policy[lane], p64 = policy[64];
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float pi = lane_f32(p, i);
+        if (ALL || ((mask >> i) & 1ULL)) sum += (double)pi;
+    }
+    if (ALL || pass_ok) sum += (double)p64;
+    ChildRec *recs = P.stats + node_row * MZ_ACTIONS;
+    const bool ex = ALL || ((mask >> lane) & 1ULL);
+    double prior = (double)p / sum, prior64 = (double)p64 / sum;
+    if (noise) {  // add_exploration_noise main.py:191-196
+        prior = prior * (1 - frac) + noise[lane] * frac;
+        prior64 = prior64 * (1 - frac) + noise[64] * frac;
+    }
+    recs[lane] = ex ? ChildRec{0u, 0.0f, prior} : ChildRec{NOT_CHILD, 0.0f, 0.0};
+    if (lane == 0) recs[64] = (ALL || pass_ok) ? ChildRec{0u, 0.0f, prior64} : ChildRec{NOT_CHILD, 0.0f, 0.0};
+}
+
+// ---- root set-up (play_game main.py:75-83, run_mcts :100) ----------------------------------------
+__global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, const int8_t *to_play, const uint64_t *legal,
+                                                  const float *policy, const double *noise, const char *hidden) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const uint64_t mask = legal[t];
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, mask == 0, noise ? noise + (int64_t)t * MZ_ACTIONS : nullptr,
+                          cfg.noise_frac, lane);
+    const int eb = P.hidden_elem_bytes;
+    copy_hidden(P.hidden + tbase * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
+    if (lane == 0) {
+        mz_tree_meta m;
+        m.n_nodes = 1;
+        m.root_n = 0;
+        m.root_w = 0.0f;
+        m.root_player = to_play[t];
+        m.mm_min = cfg.bounds_none ? (double)INFINITY : cfg.bound_lo;  // utilities.py:117-119
+        m.mm_max = cfg.bounds_none ? -(double)INFINITY : cfg.bound_hi;
+        m.mm_flags = 0;
+        m.path_len = 0;
+        m.leaf_player = 0;
+        m.error = 0;
+        m.leaf_parent = 0;
+        m.leaf_action = 0;
+        m.pad[0] = m.pad[1] = 0;
+        P.meta[t] = m;
+    }
+}
+
+// ---- one simulation's descent (run_mcts main.py:103-118) ------------------------------------------
+__device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &cfg, char *net_in, int t, int lane) {
+    mz_tree_meta *meta = &P.meta[t];
+    const MinMax mm = load_minmax(meta);
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    int node = 0, depth = 0, a = 0;
+    uint32_t np = (uint32_t)meta->root_n;
+    int player = meta->root_player;
+    const bool tie_lowest = cfg.tie_lowest != 0;
+    for (;;) {
+        const ChildRec *recs = P.stats + (tbase + node) * MZ_ACTIONS;
+        const ChildRec r = recs[lane];
+        const ChildRec r64 = recs[64];
+        const PbcRec pb = P.pbc[np];
+        const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+        a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
+        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
+        if (lane == 0) P.path[tbase + depth] = PathRec{(uint16_t)node, (uint8_t)a, 0};
+        ++depth;
+        player = -player;  // children belong to the other player (main.py:173)
+        const uint32_t child = nc >> 16;
+        if (child == 0 || depth >= P.max_nodes) break;  // Node.expanded() false -> leaf
+        node = (int)child - 1;
+        np = nc & 0xFFFFu;
+    }
+    if (lane == 0) {
+        meta->path_len = depth;
+        meta->leaf_player = player;
+        meta->leaf_parent = node;
+        meta->leaf_action = a;
+    }
+    // network input row: parent hidden (8 planes) ++ Action(a, child's player).encode() (2 planes)
+    const int eb = P.hidden_elem_bytes;
+    char *row = net_in + (int64_t)t * (640 * eb);
+    copy_hidden(row, P.hidden + (tbase + node) * (int64_t)(MZ_HIDDEN_ELEMS * eb), eb, lane);
+    const int layer = lane >> 5, cell = (2 * lane) & 63, my_layer = player == 1 ? 0 : 1;
+    const bool set = layer == my_layer && ((encode_rows(a) >> (cell >> 3)) & 1u);
+    if (eb == 4)
+        ((float2 *)(row + 512 * 4))[lane] = set ? make_float2(1.0f, 1.0f) : make_float2(0.0f, 0.0f);
+    else
+        ((uint32_t *)(row + 512 * 2))[lane] = set ? P.one16x2 : 0u;
+}
+
+// ---- expand the leaf + backpropagate (main.py:123-125, 165-175, 180-186) --------------------------
+__device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_search_cfg &cfg, const float *value, const float *policy,
+                                                   const char *hidden, int t, int lane) {
+    mz_tree_meta *meta = &P.meta[t];
+    const int new_id = meta->n_nodes, depth = meta->path_len;
+    if (new_id >= P.max_nodes || depth < 1) {  // pool full (or no select before): flag, leave the tree untouched
+        if (lane == 0) meta->error |= 1;
+        return;
+    }
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    write_children<true>(P, tbase + new_id, policy + (int64_t)t * MZ_ACTIONS, ~0ULL, true, nullptr, 0.0, lane);
+    const int eb = P.hidden_elem_bytes;
+    copy_hidden(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
+
+    // backpropagate: search_path[k], k = 0..depth (root .. leaf); node k>=1 lives in its parent's
+    // child record (path[k-1].node, path[k-1].action).  Players alternate with depth, so node k has
+    // the leaf's player iff (depth-k) is even.  value_k = value after k times `reward + discount*value`.
+    const float v0 = value[t], disc = (float)cfg.discount;
+    MinMax mm = load_minmax(meta);
+    float vmin = INFINITY, vmax = -INFINITY;
+    for (int k0 = 0; k0 <= depth; k0 += 64) {
+        const int k = k0 + lane;
+        if (k <= depth) {
+            float v = v0;
+            for (int i = 0; i < k; ++i) v = 0.0f + disc * v;  // node.reward (0) + discount * value
+            const float sv = ((depth - k) & 1) ? -v : v;
+            float nv;
+            if (k == 0) {
+                const float w = meta->root_w + sv;
+                const int n = meta->root_n + 1;
+                meta->root_w = w;
+                meta->root_n = n;
+                nv = w / (float)n;
+            } else {
+                const PathRec pr = P.path[tbase + k - 1];
+                ChildRec *rec = P.stats + (tbase + pr.node) * MZ_ACTIONS + pr.action;
+                uint32_t nc = rec->nc + 1u;
+                const float w = rec->w + sv;
+                if (k == depth) nc |= (uint32_t)(new_id + 1) << 16;  // the leaf is expanded now
+                rec->nc = nc;
+                rec->w = w;
+                nv = w / (float)(nc & 0xFFFFu);
+            }
+            vmin = fminf(vmin, nv);
+            vmax = fmaxf(vmax, nv);
+        }
+    }
+    // MinMaxStats.update (utilities.py:121-123) with every node.value() of the path; builtin
+    // min/max replace only on strictly smaller/greater, which is order independent.
+    vmin = wave_min_f32(vmin);
+    vmax = wave_max_f32(vmax);
+    if (lane == 0) {
+        int f = meta->mm_flags;
+        if (mx_lt(mx_t(vmin), mm.lo)) { meta->mm_min = (double)vmin; f |= 1; }
+        if (mx_gt(mx_t(vmax), mm.hi)) { meta->mm_max = (double)vmax; f |= 2; }
+        meta->mm_flags = f;
+        meta->n_nodes = new_id + 1;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_select(Pool P, mz_search_cfg cfg, char *net_in) {
+    tree_select(P, cfg, net_in, blockIdx.x, threadIdx.x);
+}
+__global__ void __launch_bounds__(64) k_expand_backup(Pool P, mz_search_cfg cfg, const float *value, const float *policy,
+                                                      const char *hidden) {
+    tree_expand_backup(P, cfg, value, policy, hidden, blockIdx.x, threadIdx.x);
+}
+__global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg, const float *value, const float *policy,
+                                                      const char *hidden, char *net_in) {
+    tree_expand_backup(P, cfg, value, policy, hidden, blockIdx.x, threadIdx.x);
+    // the descent re-reads records other lanes of this wave have just written: make them visible
+    // within the workgroup (one wave) before reading
+    __syncthreads();
+    tree_select(P, cfg, net_in, blockIdx.x, threadIdx.x);
+}
+
+__global__ void __launch_bounds__(64) k_root_stats(Pool P, int32_t *visits, float *root_value, float *wsum, double *prior) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const ChildRec *recs = P.stats + (int64_t)t * P.max_nodes * MZ_ACTIONS;
+    const int64_t o = (int64_t)t * MZ_ACTIONS;
+    for (int a = lane; a < MZ_ACTIONS; a += 64) {
+        const ChildRec r = recs[a];
+        const bool ex = r.nc != NOT_CHILD;
+        visits[o + a] = ex ? (int32_t)(r.nc & 0xFFFFu) : -1;
+        if (wsum) wsum[o + a] = ex ? r.w : 0.0f;
+        if (prior) prior[o + a] = ex ? r.p : 0.0;
+    }
+    if (lane == 0) {
+        const mz_tree_meta *m = &P.meta[t];
+        root_value[t] = m->root_n ? m->root_w / (float)m->root_n : 0.0f;  // Node.value()
+    }
+}
+
+// select_action main.py:128-140 + softmax_sample :275-285, one lane per game
+__global__ void __launch_bounds__(256) k_select_action(const int32_t *visits, const int32_t *num_moves, int num_moves_all, const double *u,
+                                                       uint8_t *action, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int32_t *v = visits + g * MZ_ACTIONS;
+    const int moves = num_moves ? num_moves[g] : num_moves_all;
+    int64_t sum = 0;
+    int best = -1, bestv = -1, last = -1;
+    for (int a = 0; a < MZ_ACTIONS; ++a) {
+        const int x = v[a];
+        if (x < 0) continue;
+        sum += x;
+        last = a;
+        if (x > bestv) { bestv = x; best = a; }  // first maximum in children (ascending) order
+    }
+    int out = best;
+    if (moves < 20 && best >= 0) {
+        // np.random.choice(actions, p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+        const double uu = u[g], dsum = (double)sum;
+        double c = 0.0;
+        for (int a = 0; a < MZ_ACTIONS; ++a)
+            if (v[a] >= 0) c += (double)v[a] / dsum;
+        const double total = c;
+        c = 0.0;
+        out = last;
+        for (int a = 0; a < MZ_ACTIONS; ++a) {
+            if (v[a] < 0) continue;
+            c += (double)v[a] / dsum;
+            if (!(c / total <= uu)) { out = a; break; }
+        }
+    }
+    action[g] = (uint8_t)(out < 0 ? 64 : out);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int mz_pool_layout_compute(int32_t n_trees, int32_t max_nodes, int32_t hidden_dtype, mz_pool_layout *out) {
+    MZ_REQUIRE(out, "mz_pool_layout_compute: null out");
+    MZ_REQUIRE(n_trees >= 1, "mz_pool_layout_compute: n_trees < 1");
+    MZ_REQUIRE(max_nodes >= 2 && max_nodes <= 65534, "mz_pool_layout_compute: max_nodes %d outside [2, 65534]", max_nodes);
+    MZ_REQUIRE(hidden_dtype == MZ_F32 || hidden_dtype == MZ_BF16 || hidden_dtype == MZ_F16, "mz_pool_layout_compute: bad dtype");
+    static_assert(sizeof(mz_tree_meta) == 64, "mz_tree_meta must be 64 bytes");
+    static_assert(sizeof(ChildRec) == 16 && sizeof(PathRec) == 4 && sizeof(PbcRec) == 16, "record sizes");
+    mz_pool_layout L;
+    L.n_trees = n_trees;
+    L.max_nodes = max_nodes;
+    L.hidden_dtype = hidden_dtype;
+    L.hidden_elem_bytes = hidden_dtype == MZ_F32 ? 4 : 2;
+    const int64_t nodes = (int64_t)n_trees * max_nodes;
+    int64_t off = 0;
+    L.off_stats = off;  off = align_up(off + nodes * MZ_ACTIONS * 16, 256);
+    L.off_hidden = off; off = align_up(off + nodes * MZ_HIDDEN_ELEMS * L.hidden_elem_bytes, 256);
+    L.off_meta = off;   off = align_up(off + (int64_t)n_trees * 64, 256);
+    L.off_path = off;   off = align_up(off + nodes * 4, 256);
+    L.off_pbc = off;    off = align_up(off + (int64_t)(max_nodes + 1) * 16, 256);
+    L.total_bytes = off;
+    *out = L;
+    return MZ_OK;
+}
+
+static int check_pool(const char *who, const void *pool, const mz_pool_layout *L, int32_t n_trees) {
+    MZ_REQUIRE(pool && L, "%s: null pool/layout", who);
+    MZ_REQUIRE(((uintptr_t)pool & 255) == 0, "%s: pool base must be 256-byte aligned", who);
+    MZ_REQUIRE(n_trees >= 0 && n_trees <= L->n_trees, "%s: n_trees %d exceeds the pool's %d", who, n_trees, L->n_trees);
+    return MZ_OK;
+}
+
+extern "C" int mz_pool_init(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, void *stream) {
+    if (int rc = check_pool("mz_pool_init", pool, L, 0)) return rc;
+    MZ_REQUIRE(cfg, "mz_pool_init: null cfg");
+    MZ_REQUIRE(cfg->pb_c_base > 0, "mz_pool_init: pb_c_base must be > 0");
+    // ucb_score main.py:154-156: math.log / math.sqrt are libm's; evaluate them here with the same
+    // libm in double so the device never rounds a transcendental differently.
+    std::vector<PbcRec> tab((size_t)L->max_nodes + 1);
+    for (int n = 0; n <= L->max_nodes; ++n) {
+        tab[(size_t)n].a = log(((double)n + cfg->pb_c_base + 1) / cfg->pb_c_base) + cfg->pb_c_init;
+        tab[(size_t)n].s = sqrt((double)n);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    MZ_HIP(hipMemcpyAsync((char *)pool + L->off_pbc, tab.data(), tab.size() * sizeof(PbcRec), hipMemcpyHostToDevice, s));
+    MZ_HIP(hipStreamSynchronize(s));  // tab is a host temporary
+    MZ_HIP(hipMemsetAsync((char *)pool + L->off_meta, 0, (size_t)L->n_trees * 64, s));
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_root_init(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const int8_t *to_play,
+                                 const uint64_t *legal, const float *policy, const double *noise, const void *hidden, int32_t n_trees,
+                                 void *stream) {
+    if (int rc = check_pool("mz_mcts_root_init", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && to_play && legal && policy && hidden, "mz_mcts_root_init: null pointer");
+    hipLaunchKernelGGL(k_root_init, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, to_play, legal, policy,
+                       noise, (const char *)hidden);
+    MZ_LAUNCH_CHECK("k_root_init");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_select(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, void *net_in, int32_t n_trees,
+                              void *stream) {
+    if (int rc = check_pool("mz_mcts_select", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && net_in, "mz_mcts_select: null pointer");
+    hipLaunchKernelGGL(k_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, (char *)net_in);
+    MZ_LAUNCH_CHECK("k_select");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_expand_backup(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const float *value,
+                                     const float *policy, const void *hidden, int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_expand_backup", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && value && policy && hidden, "mz_mcts_expand_backup: null pointer");
+    hipLaunchKernelGGL(k_expand_backup, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value, policy,
+                       (const char *)hidden);
+    MZ_LAUNCH_CHECK("k_expand_backup");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_backup_select(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const float *value,
+                                     const float *policy, const void *hidden, void *net_in, int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_backup_select", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && value && policy && hidden && net_in, "mz_mcts_backup_select: null pointer");
+    hipLaunchKernelGGL(k_backup_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value, policy,
+                       (const char *)hidden, (char *)net_in);
+    MZ_LAUNCH_CHECK("k_backup_select");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_root_stats(const void *pool, const mz_pool_layout *L, int32_t *visits, float *root_value, float *wsum,
+                                  double *prior, int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_root_stats", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(visits && root_value, "mz_mcts_root_stats: null pointer");
+    hipLaunchKernelGGL(k_root_stats, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), visits, root_value, wsum, prior);
+    MZ_LAUNCH_CHECK("k_root_stats");
+    return MZ_OK;
+}
+
+extern "C" int mz_select_action(const int32_t *visits, const int32_t *num_moves, int32_t num_moves_all, const double *u,
+                                uint8_t *action, int64_t n, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_select_action: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(visits && u && action, "mz_select_action: null pointer");
+    hipLaunchKernelGGL(k_select_action, dim3(mz_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, visits, num_moves, (int)num_moves_all,
+                       u, action, n);
+    MZ_LAUNCH_CHECK("k_select_action");
+    return MZ_OK;
+}

@@ -1,0 +1,127 @@
+"""BatchedMCTS -- n independent MuZero searches, one wavefront per tree, node pool in HBM.
+
+Device-side counterpart of reference main.py:99-196 (run_mcts and helpers), reversi.py:234-251
+(Node) and utilities.py:114-129 (MinMaxStats).  The network stays PyTorch: the search hands over
+``net_in`` (n,10,8,8) and takes back (value, policy, hidden) once per simulation.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import config
+
+
+# int32 column of each mz_tree_meta field in BatchedMCTS.meta() (include/muzero_amd.h)
+META_N_NODES, META_ROOT_N, META_ROOT_W, META_ROOT_PLAYER = 0, 1, 2, 3
+META_MM_FLAGS, META_PATH_LEN, META_LEAF_PLAYER, META_ERROR, META_LEAF_PARENT, META_LEAF_ACTION = 8, 9, 10, 11, 12, 13
+
+
+def search_cfg(cfg=None):
+    """mz_search_cfg from the config module (read at call time, like the reference)."""
+    c = cfg or config
+    kb = c.known_bounds
+    return L.SearchCfg(pb_c_base=float(c.pb_c_base), pb_c_init=float(c.pb_c_init), discount=float(c.discount),
+                       noise_frac=float(c.root_exploration_fraction), bound_lo=float(kb[0]) if kb else 0.0,
+                       bound_hi=float(kb[1]) if kb else 0.0, bounds_none=int(kb is None),
+                       tie_lowest=int(bool(getattr(c, "tie_break_lowest", False))))
+
+
+class BatchedMCTS:
+    def __init__(self, n_trees, max_sims, hidden_dtype=torch.float32, device="cuda", cfg=None):
+        self.n = int(n_trees)
+        self.max_sims = int(max_sims)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.MzError("BatchedMCTS needs a GPU device (no CPU fallback)")
+        self.hidden_dtype = hidden_dtype
+        self.layout = L.PoolLayout()
+        L.call("mz_pool_layout_compute", self.n, self.max_sims + 1, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[hidden_dtype],
+               C.byref(self.layout))
+        self.pool = torch.empty(self.layout.total_bytes, dtype=torch.uint8, device=self.device)
+        assert self.pool.data_ptr() % 256 == 0
+        self.cfg = search_cfg(cfg)
+        L.call("mz_pool_init", L.dptr(self.pool), C.byref(self.layout), C.byref(self.cfg), L.current_stream())
+        self.net_in = torch.zeros((self.n, 10, 8, 8), dtype=hidden_dtype, device=self.device)
+        self.sims_done = 0
+
+    # views for the network call (network.py:155-163 takes hidden and action separately)
+    @property
+    def hidden_in(self):
+        return self.net_in[:, :8]
+
+    @property
+    def action_in(self):
+        return self.net_in[:, 8:]
+
+    def _args(self):
+        return L.dptr(self.pool), C.byref(self.layout), C.byref(self.cfg)
+
+    def root_init(self, to_play, legal, policy, hidden, noise=None):
+        """play_game main.py:75-83: root expansion over legal actions + exploration noise.
+        to_play int8 (n,), legal int64 (n,), policy f32 (n,65), hidden (n,8,8,8), noise f64 (n,65) by action."""
+        self._check(policy, hidden)
+        L.call("mz_mcts_root_init", *self._args(), L.dptr(to_play), L.dptr(legal), L.dptr(policy), L.dptr(noise),
+               L.dptr(hidden), self.n, L.current_stream())
+        self.sims_done = 0
+
+    def select(self):
+        """descent of one simulation for every tree; fills self.net_in"""
+        L.call("mz_mcts_select", *self._args(), L.dptr(self.net_in), self.n, L.current_stream())
+
+    def expand_backup(self, value, policy, hidden):
+        self._check(policy, hidden, value)
+        self._count()
+        L.call("mz_mcts_expand_backup", *self._args(), L.dptr(value), L.dptr(policy), L.dptr(hidden), self.n,
+               L.current_stream())
+
+    def backup_select(self, value, policy, hidden):
+        """expand_backup of this simulation fused with select of the next one"""
+        self._check(policy, hidden, value)
+        self._count()
+        L.call("mz_mcts_backup_select", *self._args(), L.dptr(value), L.dptr(policy), L.dptr(hidden),
+               L.dptr(self.net_in), self.n, L.current_stream())
+
+    def root_stats(self, with_debug=False):
+        visits = torch.empty((self.n, 65), dtype=torch.int32, device=self.device)
+        root_value = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        wsum = torch.empty((self.n, 65), dtype=torch.float32, device=self.device) if with_debug else None
+        prior = torch.empty((self.n, 65), dtype=torch.float64, device=self.device) if with_debug else None
+        L.call("mz_mcts_root_stats", L.dptr(self.pool), C.byref(self.layout), L.dptr(visits), L.dptr(root_value), L.dptr(wsum), L.dptr(prior),
+               self.n, L.current_stream())
+        return (visits, root_value, wsum, prior) if with_debug else (visits, root_value)
+
+    def meta(self):
+        """(n,16) int32 view of the mz_tree_meta records (tests / debugging)"""
+        o = self.layout.off_meta
+        return self.pool[o:o + self.n * 64].view(torch.int32).view(self.n, 16)
+
+    def path(self):
+        """(n, max_nodes, 4) uint8 view of the path records {u16 node, u8 action, pad}"""
+        o = self.layout.off_path
+        m = self.layout.max_nodes
+        return self.pool[o:o + self.n * m * 4].view(self.n, m, 4)
+
+    def _count(self):
+        if self.sims_done >= self.max_sims:
+            raise L.MzError("pool sized for %d simulations per tree is full" % self.max_sims)
+        self.sims_done += 1
+
+    def _check(self, policy, hidden, value=None):
+        if policy.dtype != torch.float32 or tuple(policy.shape) != (self.n, 65):
+            raise L.MzError("policy must be float32 (n,65)")
+        if hidden.dtype != self.hidden_dtype or hidden.numel() != self.n * 512:
+            raise L.MzError("hidden must be %s with n*512 elements" % self.hidden_dtype)
+        if value is not None and (value.dtype != torch.float32 or value.numel() != self.n):
+            raise L.MzError("value must be float32 with n elements")
+
+
+def select_action(visits, num_moves, u):
+    """select_action + softmax_sample (main.py:128-140, 275-285) for n searches.
+    visits int32 (n,65) (-1 = not a child); num_moves int or int32 (n,); u float64 (n,) uniforms."""
+    n = visits.shape[0]
+    out = torch.empty(n, dtype=torch.uint8, device=visits.device)
+    per = num_moves if torch.is_tensor(num_moves) else None
+    L.call("mz_select_action", L.dptr(visits), L.dptr(per), 0 if per is not None else int(num_moves), L.dptr(u),
+           L.dptr(out), n, L.current_stream())
+    return out

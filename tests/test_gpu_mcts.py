@@ -1,0 +1,208 @@
+"""GPU parity of the HIP tree-search kernels (through the C ABI): identical simulation paths and
+visit counts vs the reference fixtures, and vs the C oracle at BASELINE config-3 size, with
+bit-identical W (fp32) and priors (double).  Root values: bit-identical (bar: 1e-5 relative)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import refspec as R  # noqa: E402
+from hashnet_torch import HashNetTorch  # noqa: E402
+from oracle import mz_oracle as O  # noqa: E402  (checker only)
+from muzero_amd import mcts as MC  # noqa: E402
+
+MODE_NAME = {v: k for k, v in R.MODES.items()}
+
+
+def dev(a):
+    if a.dtype == np.uint64:
+        a = a.view(np.int64)
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Cfg:
+    """a config-module stand-in so tests can vary knobs without touching muzero_amd.config"""
+    pb_c_base, pb_c_init, discount, root_exploration_fraction = 19652, 1.25, 1.0, 0.25
+    known_bounds = (-1, 1)
+    tie_break_lowest = False
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "mcts_traces.npz"))
+
+
+def case_paths(fx, i):
+    s0, s1 = fx["sim_off"][i], fx["sim_off"][i + 1]
+    off = fx["path_off"]
+    return [fx["path_actions"][off[s]:off[s + 1]] for s in range(s0, s1)]
+
+
+def gpu_paths(m):
+    meta = m.meta().cpu().numpy()
+    path = m.path().cpu().numpy()
+    out = []
+    for t in range(m.n):
+        d = meta[t, MC.META_PATH_LEN]
+        out.append(path[t, :d, 2].copy())
+    return out
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_reference_fixture_searches(fx, fused):
+    """every fixture search (HashNet modes, recorded real-network outputs, known_bounds None /
+    replaced bounds, discount != 1, pass-only root): per-simulation paths, visits, W, priors"""
+    from muzero_amd.mcts import BatchedMCTS, select_action
+    n_cases = len(fx["S"])
+    for i in range(n_cases):
+        S = int(fx["S"][i])
+        bounds = None if fx["bounds_none"][i] else (float(fx["bound_lo"][i]), float(fx["bound_hi"][i]))
+        cfg = Cfg(discount=float(fx["discount"][i]), known_bounds=bounds)
+        n = 3  # three copies of the same tree: lanes/waves must not interact
+        m = BatchedMCTS(n, S, cfg=cfg)
+        kind = int(fx["kind"][i])
+        net = HashNetTorch(MODE_NAME[int(fx["mode"][i])]) if kind == 0 else None
+        rep = lambda a: dev(np.repeat(np.asarray(a)[None], n, 0))  # noqa: E731
+        if kind == 0:
+            v0, p0, h0 = net.initial_inference(rep(fx["image"][i]).float())
+            assert (p0[0].cpu().numpy() == fx["root_policy"][i]).all()
+        else:
+            p0, h0 = rep(fx["root_policy"][i]), torch.zeros(n, 8, 8, 8, device="cuda")
+        noise = rep(fx["noise"][i]) if fx["use_noise"][i] else None
+        m.root_init(rep(fx["to_play"][i]), rep(fx["legal"][i]), p0.contiguous(), h0.contiguous(), noise)
+        want = case_paths(fx, i)
+        m.select()
+        for s in range(S):
+            got = gpu_paths(m)
+            for t in range(n):
+                assert len(got[t]) == len(want[s]) and (got[t] == want[s]).all(), ("case", i, "sim", s, got[t], want[s])
+            if kind == 0:
+                assert net.check_hidden(m.hidden_in)
+                v, p, h = net.recurrent_inference(m.hidden_in, m.action_in)
+            else:
+                k = fx["net_off"][i] + s
+                v, p, h = rep(fx["net_values"][k]), rep(fx["net_policies"][k]), torch.zeros(n, 8, 8, 8, device="cuda")
+            v, p, h = v.reshape(n).contiguous(), p.contiguous(), h.contiguous()
+            if fused and s + 1 < S:
+                m.backup_select(v, p, h)
+            else:
+                m.expand_backup(v, p, h)
+                if s + 1 < S:
+                    m.select()
+        visits, root_value, wsum, prior = (x.cpu().numpy() for x in m.root_stats(with_debug=True))
+        assert int(m.meta()[:, MC.META_ERROR].max()) == 0
+        for t in range(n):
+            assert (visits[t] == fx["visits"][i]).all(), i
+            assert wsum[t].view(np.uint32).tolist() == fx["wsum"][i].view(np.uint32).tolist(), i
+            assert (prior[t] == fx["prior"][i]).all(), i
+            assert root_value[t].view(np.uint32) == fx["root_value"][i].view(np.uint32), i
+            assert abs(float(root_value[t]) - float(fx["root_value"][i])) <= 1e-5 * abs(float(fx["root_value"][i]))
+        assert int(m.meta()[0, MC.META_ROOT_N]) == fx["root_n"][i]
+        u = dev(np.full(n, fx["u"][i], np.float64))
+        assert int(select_action(m.root_stats()[0], 30, u)[0]) == fx["greedy"][i]
+        assert int(select_action(m.root_stats()[0], 0, u)[0]) == fx["sampled"][i]
+
+
+def _roots(n, seed):
+    """n root positions reached by random playout prefixes of different lengths (oracle env)"""
+    lens = np.arange(n) % 60
+    e = O.EnvBatch(n)
+    hw = np.zeros((61, n), np.uint64); hb = np.zeros((61, n), np.uint64)
+    hw[0], hb[0] = e.white, e.black
+    for t in range(59):
+        act = np.array([O.lib().mzo_playout_action(seed, g, t, int(e.legal[g])) if t < lens[g] else 255 for g in range(n)], np.uint8)
+        e.step(act)  # 255 = illegal -> state untouched
+        hw[t + 1], hb[t + 1] = e.white, e.black
+    return e, hw, hb, lens.astype(np.int32)
+
+
+@pytest.mark.parametrize("n,S,mode,tie_lowest", [(4096, 50, "hash", False), (512, 100, "sat", False), (512, 60, "hash", True)])
+def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest):
+    """BASELINE config 3 size (4096 trees x 50 sims) on HashNet, fused backup+select kernel:
+    every tree's visits / W / root value / per-sim leaf identical to the C oracle."""
+    from muzero_amd import env as menv
+    from muzero_amd.mcts import BatchedMCTS
+    e, hw, hb, lens = _roots(n, 4242)
+    img = menv.make_image(dev(hw), dev(hb), dev(lens), n)
+    net = HashNetTorch(mode)
+    v0, p0, h0 = net.initial_inference(img)
+    rng = np.random.default_rng(5)
+    noise = np.zeros((n, 65))
+    for g in range(n):
+        acts = [a for a in range(64) if (int(e.legal[g]) >> a) & 1] or [64]
+        noise[g, acts] = rng.dirichlet([0.03] * len(acts))
+    cfg = Cfg(tie_break_lowest=tie_lowest)
+    m = BatchedMCTS(n, S, cfg=cfg)
+    m.root_init(dev(e.to_play), dev(e.legal), p0.contiguous(), h0.contiguous(), dev(noise))
+    leaf_a = np.zeros((n, S), np.uint8); depth = np.zeros((n, S), np.int32)
+    m.select()
+    for s in range(S):
+        meta = m.meta()
+        leaf_a[:, s] = meta[:, MC.META_LEAF_ACTION].cpu().numpy(); depth[:, s] = meta[:, MC.META_PATH_LEN].cpu().numpy()
+        v, p, h = net.recurrent_inference(m.hidden_in, m.action_in)
+        if s + 1 < S:
+            m.backup_select(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())
+        else:
+            m.expand_backup(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())
+    visits, root_value, wsum, prior = (x.cpu().numpy() for x in m.root_stats(with_debug=True))
+    assert int(m.meta()[:, MC.META_ERROR].max()) == 0
+    imgs = img.cpu().numpy()
+    bad = 0
+    for g in range(n):
+        t = O.Tree(S, tie_lowest=tie_lowest)
+        _, odepth, oleaf = t.search_hashnet(e.to_play[g], e.legal[g], int(e.legal[g] == 0), noise[g], R.hashnet_image_hash(imgs[g]), R.MODES[mode], S)
+        ov, ow, op, orn, orv = t.root_stats()
+        ok = ((visits[g] == ov).all() and wsum[g].view(np.uint32).tolist() == ow.view(np.uint32).tolist() and (prior[g] == op).all()
+              and root_value[g].view(np.uint32) == np.float32(orv).view(np.uint32) and (leaf_a[g] == oleaf).all() and (depth[g] == odepth).all())
+        bad += not ok
+    assert bad == 0, "%d of %d trees differ from the oracle" % (bad, n)
+    assert depth.max() >= 3
+
+
+def test_select_action_vs_oracle():
+    from muzero_amd.mcts import select_action
+    rng = np.random.default_rng(11)
+    n = 20000
+    visits = rng.integers(0, 40, (n, 65)).astype(np.int32)
+    visits[rng.random((n, 65)) < 0.7] = -1
+    visits[np.arange(n), rng.integers(0, 65, n)] = rng.integers(1, 50, n)  # at least one child with visits
+    u = rng.random(n)
+    u[:50] = 0.0
+    u[50:100] = np.nextafter(1.0, 0.0)
+    moves = rng.integers(0, 60, n).astype(np.int32)
+    got = select_action(dev(visits), dev(moves), dev(u)).cpu().numpy()
+    want = np.array([O.select_action(visits[g], moves[g], u[g]) for g in range(n)], np.uint8)
+    assert (got == want).all()
+    got0 = select_action(dev(visits), 0, dev(u)).cpu().numpy()
+    want0 = np.array([O.select_action(visits[g], 0, u[g]) for g in range(n)], np.uint8)
+    assert (got0 == want0).all()
+
+
+def test_pool_full_is_flagged_not_overrun():
+    from muzero_amd import _lib as L
+    from muzero_amd.mcts import BatchedMCTS
+    n, S = 4, 3
+    m = BatchedMCTS(n, S)
+    net = HashNetTorch("hash")
+    img = torch.zeros(n, 9, 8, 8, device="cuda"); img[:, 8] = 1
+    v0, p0, h0 = net.initial_inference(img)
+    legal = torch.full((n,), sum(1 << i for i in (19, 26, 44, 37)), dtype=torch.int64, device="cuda")
+    m.root_init(torch.full((n,), -1, dtype=torch.int8, device="cuda"), legal, p0.contiguous(), h0.contiguous())
+    for s in range(S):
+        m.select()
+        v, p, h = net.recurrent_inference(m.hidden_in, m.action_in)
+        m.expand_backup(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())
+    with pytest.raises(L.MzError):
+        m.expand_backup(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())  # host-side guard
+    # device-side guard: bypass the host counter
+    m.sims_done = 0
+    m.select()
+    m.expand_backup(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())
+    assert bool((m.meta()[:, MC.META_ERROR] & 1).all()) and int(m.meta()[0, MC.META_N_NODES]) == S + 1
