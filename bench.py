@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- MCTS simulations/s (+ env steps/s, self-play games/s) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): 4096 game trees per GPU x 50 simulations, random-init MuZero
+network (seed 1261), PyTorch-ROCm inference once per simulation on the whole leaf batch, roots =
+positions reached after 0..59 random moves.  One "step" = one complete search of every tree on the
+rank: initial inference + root expansion with Dirichlet noise + 50 x (recurrent inference + fused
+expand/backup/select kernel) + root statistics.  Inputs are resident in HBM before the timed region.
+Games shard across ranks with no data-path collective (weak scaling: 4096 trees per GPU).
+
+Extra legs, reported in the same JSON line and NOT part of `value`:
+  env        configs[1]: 1,048,576 random-play games x 60 steps; fused in-register playout kernel
+             and the HBM-resident step kernel (roofline_env is for the latter)
+  selfplay   --selfplay-games G: G whole games of 60 moves through the batched engine -> games/s
+  roofline   dominant hand-written kernel of the timed region (k_backup_select), HIP-event timed
+  cpu_baseline  the C oracle (tree search) + PyTorch CPU inference on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+F32_PEAK_TFLOPS = 157.3
+NET_MFLOP = 116.0            # MFLOP per inference sample
+ENV_BYTES_PER_STEP = 46
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trees", type=int, default=4096, help="game trees per GPU")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--env-games", type=int, default=1 << 20)
+    ap.add_argument("--selfplay-games", type=int, default=1024)
+    ap.add_argument("--selfplay-sims", type=int, default=50)
+    ap.add_argument("--skip-extras", action="store_true", help="only the timed MCTS leg")
+    ap.add_argument("--cpu-trees", type=int, default=4096)
+    return ap.parse_args()
+
+
+def make_roots(n, seed, game0, device):
+    """positions after (g mod 60) random moves of game g, with their observation history"""
+    from muzero_amd.env import BatchedEnv
+    e = BatchedEnv(n, device)
+    hw = torch.zeros((61, n), dtype=torch.int64, device=device)
+    hb = torch.zeros((61, n), dtype=torch.int64, device=device)
+    hw[0], hb[0] = e.white, e.black
+    act = torch.empty(n, dtype=torch.uint8, device=device)
+    for t in range(60):
+        e.random_action(seed, game0, t, out=act)
+        e.step(act)
+        hw[t + 1], hb[t + 1] = e.white, e.black
+    idx = (torch.arange(n, device=device) % 60).to(torch.int32)
+    gi = torch.arange(n, device=device)
+    r = BatchedEnv(n, device)
+    r.white.copy_(hw[idx.long(), gi])
+    r.black.copy_(hb[idx.long(), gi])
+    r.to_play.copy_(torch.where(idx % 2 == 0, -1, 1).to(torch.int8))  # every step switches the mover
+    r.steps.copy_(idx.to(torch.uint8))
+    r.legal.copy_(r.legal_mask())
+    return r, hw, hb, idx
+
+
+def event_time_ms(fn, iters):
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def bench_env(args, device):
+    from muzero_amd.env import BatchedEnv
+    n = args.env_games
+    e = BatchedEnv(n, device)
+    e.random_playout(1261, 0, 60, 0)
+    torch.cuda.synchronize()
+    ms_fused = event_time_ms(lambda: e.random_playout(1261, 0, 60, 0), 5)
+    # HBM-resident path: one k_env_step launch per step over states in HBM (actions precomputed)
+    e.reset()
+    acts = torch.empty((60, n), dtype=torch.uint8, device=device)
+    for t in range(60):
+        e.random_action(1261, 0, t, out=acts[t])
+        e.step(acts[t])
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot = 0.0
+    reps = 3
+    for _ in range(reps):
+        e.reset()
+        start.record()
+        for t in range(60):
+            e.step(acts[t])
+        end.record()
+        end.synchronize()
+        tot += start.elapsed_time(end)
+    ms_step = tot / (reps * 60)
+    gbps = n * ENV_BYTES_PER_STEP / (ms_step * 1e-3) / 1e9
+    return {
+        "env_games": n,
+        "env_steps_per_sec_fused_playout": n * 60 / (ms_fused * 1e-3),
+        "env_steps_per_sec_step_kernel": n / (ms_step * 1e-3),
+        "roofline_env": {"kernel": "k_env_step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_step": ENV_BYTES_PER_STEP,
+                         "us_per_launch": ms_step * 1e3},
+    }
+
+
+def bench_cpu_baseline(args):
+    """C oracle tree search + PyTorch CPU inference on the host cores (bounded sample)."""
+    import numpy as np
+    from oracle import mz_oracle as O
+    from muzero_amd.network import Network
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    torch.manual_seed(1261)
+    net = Network().eval()
+    n, S = args.cpu_trees, args.sims
+    trees = [O.Tree(S) for _ in range(n)]
+    legal = sum(1 << i for i in (19, 26, 44, 37))
+    img = torch.zeros(n, 9, 8, 8)
+    img[:, 8] = 1
+    rng = np.random.default_rng(0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        v, p, h = net.initial_inference(img)
+        hid = {0: h}
+        pn = p.numpy()
+        for g, t in enumerate(trees):
+            noise = np.zeros(65)
+            noise[[19, 26, 44, 37]] = rng.dirichlet([0.03] * 4)
+            t.root_init(-1, legal, 0, pn[g], noise)
+        pool = torch.zeros(S + 1, n, 8, 8, 8)
+        pool[0] = h
+        x = torch.zeros(n, 10, 8, 8)
+        for s in range(S):
+            for g, t in enumerate(trees):
+                d, pid, a, plane, _ = t.select()
+                x[g, :8] = pool[pid, g]
+                x[g, 8:] = torch.from_numpy(O.action_encode(a, 1 if plane == 0 else -1).astype(np.float32))
+            v, p, h = net.recurrent_inference_packed(x)
+            pool[s + 1] = h
+            vn, pn = v.numpy().reshape(-1), p.numpy()
+            for g, t in enumerate(trees):
+                t.expand_backup(vn[g], pn[g])
+    dt = time.perf_counter() - t0
+    return {"value": n * S / dt, "unit": "simulations/s", "cores": threads, "kind": "port",
+            "sample": "%d trees x %d sims from the opening: C oracle (oracle/mz_oracle.c) tree search + PyTorch CPU fp32 "
+                      "inference, batch %d, %.1f s" % (n, S, n, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from muzero_amd.env import make_image
+    from muzero_amd.network import InferenceEngine, Network
+    from muzero_amd.selfplay import SelfPlayEngine
+
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
+    torch.manual_seed(1261)  # main.py:18: identical random-init weights on every rank
+    net = InferenceEngine(Network(), args.trees, dtype)
+    n, S = args.trees, args.sims
+    eng = SelfPlayEngine(n, net, num_simulations=S, device=device, use_graph=not args.no_graph, seed=1261 + rank)
+    roots, hw, hb, idx = make_roots(n, 1261, rank * n, device)
+    eng.env = roots
+    image = make_image(hw, hb, idx, n, dtype)
+
+    def step():
+        return eng.search(image)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    sims = args.steps * n * S * world
+    out = {
+        "metric": "mcts_simulations_per_sec", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d game trees per GPU x %d simulations per search; random-init MuZero net "
+                               "(seed 1261), PyTorch-ROCm %s inference on the whole leaf batch; roots = positions after 0..59 "
+                               "random moves; tree arithmetic f64/f32 as the reference" % (n, S, args.dtype),
+                   "trees_per_gpu": n, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "games sharded x%d" % world},
+    }
+
+    if rank == 0 and world == 1 and not args.skip_extras:
+        # ---- roofline of the dominant hand-written kernel: k_backup_select, HIP-event timed on the launch stream
+        from muzero_amd import _lib as L
+        from muzero_amd import mcts as MC
+        v, p, h = net.recurrent(eng.mcts.net_in)
+        h = h.reshape(n, 8, 8, 8).contiguous()
+        noise = eng.dirichlet_noise(roots.legal)
+        v0, p0, h0 = net.initial(image)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot_ms, depth_sum, launches = 0.0, 0.0, 0
+        for rep in range(3):
+            eng.mcts.root_init(roots.to_play, roots.legal, p0, h0.reshape(n, 8, 8, 8).contiguous(), noise)
+            eng.mcts.select()
+            for s in range(S - 1):
+                # feed real network outputs so the trees grow as in the timed region; time only the kernel
+                v, p, h = net.recurrent(eng.mcts.net_in)
+                h = h.reshape(n, 8, 8, 8).contiguous()
+                depth_sum += float(eng.mcts.meta()[:, MC.META_PATH_LEN].float().mean()) if rep == 0 else 0.0
+                start.record()
+                eng.mcts.backup_select(v, p, h)
+                end.record()
+                end.synchronize()
+                tot_ms += start.elapsed_time(end)
+                launches += 1
+            eng.mcts.sims_done = 0
+        d = depth_sum / (S - 1)
+        eb = 2 if dtype != torch.float32 else 4
+        # algorithmic bytes per simulation: descent d x 65 x 16 B; expansion 260+4 B in, 65 x 16 B out;
+        # backup (d+1) x 16 B r/w; path/leaf records 16 B; hidden state: copy-in 2 x 512 x eb, gather 512 x eb in + 640 x eb out
+        tree_bytes = 1040.0 * d + 1040 + 264 + 16.0 * (d + 1) + 16
+        hid_bytes = (2 * 512 + 512 + 640) * eb
+        us = tot_ms / launches * 1e3
+        gbps = n * (tree_bytes + hid_bytes) / (us * 1e-6) / 1e9
+        out["roofline"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": us, "mean_depth": d,
+                           "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes, "trees_per_launch": n}
+        # ---- inference share: the same S-1 recurrent calls alone
+        ms_net = event_time_ms(lambda: net.recurrent(eng.mcts.net_in), 20)
+        tf = n * NET_MFLOP * 1e6 / (ms_net * 1e-3) / 1e12
+        peak = F32_PEAK_TFLOPS if dtype == torch.float32 else BF16_PEAK_TFLOPS
+        out["roofline_net"] = {"kernel": "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf,
+                               "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ms_per_call": ms_net, "batch": n}
+        out.update(bench_env(args, device))
+        if args.selfplay_games > 0:
+            g = args.selfplay_games
+            net_sp = InferenceEngine(Network(), g, dtype)
+            sp = SelfPlayEngine(g, net_sp, num_simulations=args.selfplay_sims, device=device, use_graph=not args.no_graph)
+            sp.play_games(max_moves=2)  # warm-up: graph capture, kernel selection
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rec = sp.play_games()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            out["selfplay"] = {"games": g, "simulations": args.selfplay_sims, "moves": rec.length, "seconds": dts,
+                               "games_per_sec": g / dts, "simulations_per_sec": g * rec.length * args.selfplay_sims / dts}
+        out["cpu_baseline"] = bench_cpu_baseline(args)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+"""MuZero networks for 8x8 reversi -- PyTorch-ROCm (the only dense contraction of the engine).
+
+Architecture and ``state_dict`` key names follow reference network.py:35-167 so checkpoints move
+between the two code bases unchanged (``representation.conv1.0.weight`` ...
+``dynamics.conv.0.weight`` ... ``prediction.value_head.3.bias``); 1,836,526 parameters.
+What is added for the batched engine:
+
+  * ``recurrent_inference_packed(x10)`` takes the (B,10,8,8) tensor the select kernel writes
+    (hidden planes ++ action planes) so no ``torch.cat`` copy is needed per simulation;
+  * ``InferenceEngine`` wraps a network for serving the search: dtype (fp32 for parity runs, bf16
+    for throughput), channels_last memory format, fp32 value/policy heads' outputs, and a
+    hipGraph (torch.cuda.CUDAGraph) capture of the whole per-simulation step.
+
+Return contract (network.py:146-163): ``(value (B,1), policy (B,65) softmaxed, hidden (B,8,8,8))``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import config
+
+BOARD_CELLS = 64
+HIDDEN_PLANES = 8
+
+
+def _conv3x3(cin, cout, bias=True):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
+
+
+class ResidualBlock(nn.Module):
+    """relu(x + conv(relu(conv(x))))  -- network.py:35-47 (no batch norm in the reference)"""
+
+    def __init__(self, filters):
+        super().__init__()
+        self.block = nn.Sequential(_conv3x3(filters, filters), nn.ReLU(), _conv3x3(filters, filters))
+
+    def forward(self, x):
+        return F.relu(x + self.block(x))
+
+
+def _tower(filters):
+    return [ResidualBlock(filters) for _ in range(3)]
+
+
+class Representation(nn.Module):
+    """observation (9,8,8) -> hidden (8,8,8)  -- network.py:49-77"""
+
+    def __init__(self, num_channels=None):
+        super().__init__()
+        c = num_channels or config.num_channels
+        self.conv1 = nn.Sequential(_conv3x3(config.state_shape[0], c), nn.ReLU())
+        self.conv2 = nn.Sequential(*_tower(c))
+        self.conv3 = nn.Sequential(_conv3x3(c, HIDDEN_PLANES), nn.ReLU())
+
+    def forward(self, x):
+        return self.conv3(self.conv2(self.conv1(x)))
+
+
+class Dynamics(nn.Module):
+    """(hidden ++ action planes) (10,8,8) -> next hidden (8,8,8); first/last conv without bias
+    -- network.py:113-135"""
+
+    def __init__(self, num_channels=None):
+        super().__init__()
+        c = num_channels or config.num_channels
+        self.conv = nn.Sequential(_conv3x3(HIDDEN_PLANES + 2, c, bias=False), nn.ReLU(), *_tower(c),
+                                  _conv3x3(c, HIDDEN_PLANES, bias=False), nn.ReLU())
+
+    def forward(self, rp, a):
+        return self.conv(torch.cat((rp, a), dim=1))
+
+
+class Prediction(nn.Module):
+    """hidden -> (policy softmax over 65 actions, value tanh)  -- network.py:79-111"""
+
+    def __init__(self, num_channels=None):
+        super().__init__()
+        self.board_size = BOARD_CELLS
+        self.flatten = nn.Flatten()
+        self.policy_head = nn.Sequential(nn.Conv2d(HIDDEN_PLANES, 2, 1, 1), nn.ReLU(), nn.Flatten(),
+                                         nn.Linear(2 * BOARD_CELLS, 2 * BOARD_CELLS), nn.ReLU(),
+                                         nn.Linear(2 * BOARD_CELLS, config.action_space_size), nn.Softmax(dim=1))
+        self.value_head = nn.Sequential(nn.Conv2d(HIDDEN_PLANES, 2, 1, 1), nn.ReLU(), nn.Flatten(),
+                                        nn.Linear(2 * BOARD_CELLS, 1), nn.Tanh())
+
+    def forward(self, x):
+        return self.policy_head(x), self.value_head(x)
+
+
+class Network(nn.Module):
+    """network.py:137-167"""
+
+    def __init__(self):
+        super().__init__()
+        self.steps = 0
+        self.representation = Representation()
+        self.prediction = Prediction()
+        self.dynamics = Dynamics()
+
+    def initial_inference(self, image):
+        if image.ndim == 3:
+            image = image.unsqueeze(0)
+        hidden = self.representation(image)
+        policy, value = self.prediction(hidden)
+        return value, policy, hidden
+
+    def recurrent_inference(self, hidden_state, action):
+        if hidden_state.ndim == 3:
+            hidden_state = hidden_state.unsqueeze(0)
+        if action.ndim == 3:
+            action = action.unsqueeze(0)
+        hidden = self.dynamics(hidden_state, action)
+        policy, value = self.prediction(hidden)
+        return value, policy, hidden
+
+    def recurrent_inference_packed(self, x10):
+        """same as recurrent_inference(x10[:, :8], x10[:, 8:]) without the concatenation copy"""
+        hidden = self.dynamics.conv(x10)
+        policy, value = self.prediction(hidden)
+        return value, policy, hidden
+
+    def training_steps(self):
+        return self.steps
+
+
+class InferenceEngine:
+    """Serves a Network to the batched search: fixed batch size, fixed buffers, optional hipGraph.
+
+    ``initial(image)`` and ``recurrent(x10)`` return (value f32 (B,), policy f32 (B,65), hidden
+    (B,8,8,8) of ``dtype``, contiguous NCHW) -- exactly what the tree kernels consume.
+    """
+
+    def __init__(self, network, batch, dtype=torch.float32, channels_last=True, device="cuda"):
+        self.device = torch.device(device)
+        self.batch = int(batch)
+        self.dtype = dtype
+        self.net = network.to(self.device).eval()
+        if dtype != torch.float32:
+            self.net = self.net.to(dtype)
+        self.mf = torch.channels_last if channels_last else torch.contiguous_format
+        if channels_last:
+            self.net = self.net.to(memory_format=torch.channels_last)
+        for p in self.net.parameters():
+            p.requires_grad_(False)
+
+    def _finish(self, out):
+        value, policy, hidden = out
+        return (value.float().reshape(-1).contiguous(), policy.float().contiguous(),
+                hidden.contiguous(memory_format=torch.contiguous_format))
+
+    @torch.no_grad()
+    def initial(self, image):
+        return self._finish(self.net.initial_inference(image.to(self.dtype).contiguous(memory_format=self.mf)))
+
+    @torch.no_grad()
+    def recurrent(self, x10):
+        return self._finish(self.net.recurrent_inference_packed(x10.contiguous(memory_format=self.mf)))

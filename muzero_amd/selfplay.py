@@ -1,0 +1,170 @@
+"""Batched self-play: the per-move composition of reference main.play_game (main.py:69-92) for n
+games in lockstep on one GPU.
+
+Every game advances one real move per outer iteration.  In the reference every action (passes
+included) consumes a step and ``done`` is only set by the 60th step, so all games last exactly
+``config.max_moves`` = 60 iterations -- lockstep loses nothing.
+
+    image  = make_image(step)                    HIP   (Game.make_image, reversi.py:301-312)
+    v,p,h  = net.initial(image)                  torch (network.initial_inference)
+    root_init(to_play, legal, p, h, noise)       HIP   (expand_node + add_exploration_noise)
+    S x [ v,p,h = net.recurrent(net_in) ;        torch (network.recurrent_inference)
+          backup_select(v,p,h) ]                 HIP   (expand_node + backpropagate + next descent)
+    visits, root_value = root_stats()            HIP   (Game.store_search_statistics inputs)
+    action = select_action(visits, step, u)      HIP   (select_action / softmax_sample)
+    env.step(action)                             HIP   (Game.apply -> Environment.step)
+
+The S-loop body (network + fused tree kernel) is captured once into a hipGraph and replayed.
+Randomness (Dirichlet noise, sampling uniforms) comes from a torch generator on the device, or is
+supplied by the caller (parity tests replay the reference's own draws).
+"""
+import torch
+
+from . import _lib as L
+from . import config
+from .env import BatchedEnv, make_image
+from .mcts import BatchedMCTS, select_action
+
+
+class NetworkAdapter:
+    """serve a reference-API network (initial_inference / recurrent_inference(hidden, action))"""
+
+    def __init__(self, net):
+        self.net = net
+        self.dtype = torch.float32
+
+    @torch.no_grad()
+    def initial(self, image):
+        v, p, h = self.net.initial_inference(image)
+        return v.float().reshape(-1).contiguous(), p.float().contiguous(), h.contiguous()
+
+    @torch.no_grad()
+    def recurrent(self, x10):
+        v, p, h = self.net.recurrent_inference(x10[:, :8], x10[:, 8:])
+        return v.float().reshape(-1).contiguous(), p.float().contiguous(), h.contiguous()
+
+
+class GameRecords:
+    """Trajectories of n games (device tensors, step-major) -- the fields of reference ``Game``
+    (reversi.py:257-266): state_history, action_history, rewards, child_visits (as raw visit
+    counts, -1 = not a root child), root_values."""
+
+    def __init__(self, n, device, max_moves):
+        self.n, self.max_moves = n, max_moves
+        self.hist_white = torch.zeros((max_moves + 1, n), dtype=torch.int64, device=device)
+        self.hist_black = torch.zeros((max_moves + 1, n), dtype=torch.int64, device=device)
+        self.actions = torch.zeros((max_moves, n), dtype=torch.uint8, device=device)
+        self.rewards = torch.zeros((max_moves, n), dtype=torch.int8, device=device)
+        self.visits = torch.zeros((max_moves, n, 65), dtype=torch.int32, device=device)
+        self.root_values = torch.zeros((max_moves, n), dtype=torch.float32, device=device)
+        self.length = 0
+
+    def child_visits(self):
+        """Game.store_search_statistics (reversi.py:292-299): N_a / sum N, 0 for non-children (float64)"""
+        v = self.visits[:self.length].clamp(min=0).double()
+        return v / v.sum(-1, keepdim=True)
+
+
+class SelfPlayEngine:
+    def __init__(self, n_games, net, num_simulations=None, device="cuda", use_graph=True, seed=1261, cfg=None):
+        self.cfg = cfg or config
+        self.n = int(n_games)
+        self.S = int(num_simulations if num_simulations is not None else self.cfg.num_simulations)
+        self.device = torch.device(device)
+        self.net = net
+        self.dtype = getattr(net, "dtype", torch.float32)
+        self.env = BatchedEnv(self.n, device)
+        self.mcts = BatchedMCTS(self.n, self.S, self.dtype, device, cfg=self.cfg)
+        self.use_graph = use_graph
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+        self._graph = None
+        self._image = torch.zeros((self.n, 9, 8, 8), dtype=self.dtype, device=self.device)
+        self.sims_run = 0
+
+    # ---- randomness ------------------------------------------------------------------------------
+    def dirichlet_noise(self, legal):
+        """np.random.dirichlet([alpha]*k) over each game's legal actions (main.py:193), by action:
+        normalised Gamma(alpha) draws on the legal entries (pass column when nothing is legal)."""
+        bits = (legal.unsqueeze(1) >> torch.arange(64, device=self.device, dtype=torch.int64)) & 1
+        mask = torch.cat([bits, (legal == 0).long().unsqueeze(1)], 1).double()
+        alpha = torch.full((self.n, 65), float(self.cfg.root_dirichlet_alpha), dtype=torch.float64, device=self.device)
+        g = torch._standard_gamma(alpha, generator=self.gen).clamp_(min=1e-300) * mask
+        return (g / g.sum(1, keepdim=True)).contiguous()
+
+    # ---- one search for every game (main.py:75-87) -------------------------------------------------
+    def _sim_step(self):
+        v, p, h = self.net.recurrent(self.mcts.net_in)
+        h = h.reshape(self.n, 8, 8, 8)
+        L.call("mz_mcts_backup_select", *self.mcts._args(), L.dptr(v), L.dptr(p), L.dptr(h), L.dptr(self.mcts.net_in),
+               self.n, L.current_stream())
+        return v, p, h
+
+    def _ensure_graph(self):
+        if self._graph is not None or not self.use_graph:
+            return
+        # warm up on a side stream (allocator, MIOpen kernel selection), then capture one simulation
+        # step: network + fused tree kernel.  Capture executes nothing, so the trees are untouched;
+        # the captured outputs live in the graph's private pool and are kept alive by self._cap.
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                self.net.recurrent(self.mcts.net_in)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._cap = self._sim_step()
+        self._graph = g
+
+    def search(self, image, noise="auto"):
+        """root set-up + S simulations for all games. Returns (visits (n,65) i32, root_value (n,) f32)."""
+        v0, p0, h0 = self.net.initial(image)
+        legal, to_play = self.env.legal, self.env.to_play
+        if isinstance(noise, str):
+            noise = self.dirichlet_noise(legal)
+        self.mcts.root_init(to_play, legal, p0, h0.reshape(self.n, 8, 8, 8).contiguous(), noise)
+        S = self.S
+        if S > 0:
+            self.mcts.select()
+            if self.use_graph and S > 1:
+                self._ensure_graph()
+                for _ in range(S - 1):
+                    self._graph.replay()
+                self.mcts.sims_done += S - 1
+            else:
+                for _ in range(S - 1):
+                    v, p, h = self.net.recurrent(self.mcts.net_in)
+                    self.mcts.backup_select(v, p, h.reshape(self.n, 8, 8, 8))
+            v, p, h = self.net.recurrent(self.mcts.net_in)
+            self.mcts.expand_backup(v, p, h.reshape(self.n, 8, 8, 8).contiguous())
+            self.sims_run += S * self.n
+        return self.mcts.root_stats()
+
+    # ---- whole games (main.py:69-92) -----------------------------------------------------------------
+    def play_games(self, noise=None, u=None, max_moves=None):
+        """Play n games from the opening. noise: optional (moves, n, 65) f64 by action; u: optional
+        (moves, n) f64 uniforms for the sampled moves (both default to the engine's generator)."""
+        T = int(max_moves if max_moves is not None else self.cfg.max_moves)
+        rec = GameRecords(self.n, self.device, T)
+        env = self.env
+        env.reset()
+        rec.hist_white[0].copy_(env.white)
+        rec.hist_black[0].copy_(env.black)
+        for t in range(T):
+            make_image(rec.hist_white, rec.hist_black, t, self.n, self.dtype, out=self._image)
+            visits, root_value = self.search(self._image, noise[t].contiguous() if noise is not None else "auto")
+            ut = u[t].contiguous() if u is not None else torch.rand(self.n, dtype=torch.float64, device=self.device,
+                                                                     generator=self.gen)
+            action = select_action(visits, t, ut)  # len(action_history) == t for every game
+            reward, status = env.step(action)
+            rec.actions[t].copy_(action)
+            rec.rewards[t].copy_(reward)
+            rec.visits[t].copy_(visits)
+            rec.root_values[t].copy_(root_value)
+            rec.hist_white[t + 1].copy_(env.white)
+            rec.hist_black[t + 1].copy_(env.black)
+            rec.length = t + 1
+        rec.done = env.done.clone()
+        return rec
