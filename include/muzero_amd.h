@@ -165,10 +165,12 @@ int mz_pool_init(void *pool, const mz_pool_layout *layout, const mz_search_cfg *
  * legal_actions, initial_inference output) over the legal placements in ascending index (pass iff
  * legal == 0); add_exploration_noise with caller-supplied Dirichlet noise indexed by ACTION
  * (noise nullable = none); MinMaxStats(known_bounds) (main.py:100).
+ * pass_ok (nullable): per-tree override of "pass is a root child"; null = the game rule above
+ * (expand_node itself accepts any action list, main.py:165-175).
  * policy: (n,65) f32 rows; hidden: (n,512) of the pool's dtype; noise: (n,65) f64. */
 int mz_mcts_root_init(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
-                      const int8_t *to_play, const uint64_t *legal, const float *policy, const double *noise,
-                      const void *hidden, int32_t n_trees, void *stream);
+                      const int8_t *to_play, const uint64_t *legal, const uint8_t *pass_ok, const float *policy,
+                      const double *noise, const void *hidden, int32_t n_trees, void *stream);
 
 /* one simulation's descent for every tree (run_mcts main.py:103-118 = select_child :144-148 +
  * ucb_score :153-160 per level), one wavefront per tree.  Writes the path, and the network input
@@ -188,6 +190,22 @@ int mz_mcts_expand_backup(void *pool, const mz_pool_layout *layout, const mz_sea
 int mz_mcts_backup_select(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
                           const float *value, const float *policy, const void *hidden, void *net_in,
                           int32_t n_trees, void *stream);
+
+/* the two halves of mz_mcts_expand_backup as separate calls, for callers that keep the reference's
+ * call structure: expand_node (main.py:165-175) of the leaf reached by the last mz_mcts_select,
+ * and backpropagate (main.py:180-186) of `value` along that path. */
+int mz_mcts_expand(void *pool, const mz_pool_layout *layout, const float *policy, const void *hidden,
+                   int32_t n_trees, void *stream);
+int mz_mcts_backup(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg, const float *value,
+                   int32_t n_trees, void *stream);
+
+/* select_child (main.py:144-148) and ucb_score (main.py:153-160) of ONE expanded node per tree:
+ * action[t] = selected action of node node_id[t] (-1 if that node is not expanded);
+ * score (n,65) f64 / kind (n,65) u8 nullable together: every child's ucb score and whether the
+ * reference would hold it as a Python float (0) or an fp32 tensor (1); 255 = not a child. */
+int mz_mcts_node_scores(const void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
+                        const int32_t *node_id, int32_t *action, double *score, uint8_t *kind,
+                        int32_t n_trees, void *stream);
 
 /* root statistics after the search: visits (n,65) i32 (-1 = not a child) as consumed by
  * Game.store_search_statistics (reversi.py:292-299) and select_action (main.py:128-140);

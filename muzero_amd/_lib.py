@@ -53,10 +53,13 @@ SIGNATURES = {
     "mz_make_image": [_p, _p, _i64, _p, _i32, _p, _i32, _i64, _p],
     "mz_pool_layout_compute": [_i32, _i32, _i32, _LP],
     "mz_pool_init": [_p, _LP, _CP, _p],
-    "mz_mcts_root_init": [_p, _LP, _CP, _p, _p, _p, _p, _p, _i32, _p],
+    "mz_mcts_root_init": [_p, _LP, _CP, _p, _p, _p, _p, _p, _p, _i32, _p],
     "mz_mcts_select": [_p, _LP, _CP, _p, _i32, _p],
     "mz_mcts_expand_backup": [_p, _LP, _CP, _p, _p, _p, _i32, _p],
     "mz_mcts_backup_select": [_p, _LP, _CP, _p, _p, _p, _p, _i32, _p],
+    "mz_mcts_expand": [_p, _LP, _p, _p, _i32, _p],
+    "mz_mcts_backup": [_p, _LP, _CP, _p, _i32, _p],
+    "mz_mcts_node_scores": [_p, _LP, _CP, _p, _p, _p, _p, _i32, _p],
     "mz_mcts_root_stats": [_p, _LP, _p, _p, _p, _p, _i32, _p],
     "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
 }

@@ -192,11 +192,12 @@ __device__ __forceinline__ void write_children(const Pool &P, int64_t node_row, 
 
 // ---- root set-up (play_game main.py:75-83, run_mcts :100) ----------------------------------------
 __global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, const int8_t *to_play, const uint64_t *legal,
-                                                  const float *policy, const double *noise, const char *hidden) {
+                                                  const uint8_t *pass_ok, const float *policy, const double *noise, const char *hidden) {
     const int t = blockIdx.x, lane = threadIdx.x;
     const uint64_t mask = legal[t];
     const int64_t tbase = (int64_t)t * P.max_nodes;
-    write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, mask == 0, noise ? noise + (int64_t)t * MZ_ACTIONS : nullptr,
+    const bool pass = pass_ok ? pass_ok[t] != 0 : mask == 0;  // reversi.py:125-126: pass only when nothing else is legal
+    write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, pass, noise ? noise + (int64_t)t * MZ_ACTIONS : nullptr,
                           cfg.noise_frac, lane);
     const int eb = P.hidden_elem_bytes;
     copy_hidden(P.hidden + tbase * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
@@ -262,25 +263,38 @@ __device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &
         ((uint32_t *)(row + 512 * 2))[lane] = set ? P.one16x2 : 0u;
 }
 
-// ---- expand the leaf + backpropagate (main.py:123-125, 165-175, 180-186) --------------------------
-__device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_search_cfg &cfg, const float *value, const float *policy,
-                                                   const char *hidden, int t, int lane) {
+// ---- expand the leaf (main.py:123, 165-175) -------------------------------------------------------
+// Returns the new node's id, or -1 when the pool is full / no descent preceded (flagged in meta).
+__device__ __forceinline__ int tree_expand(const Pool &P, const float *policy, const char *hidden, int t, int lane) {
     mz_tree_meta *meta = &P.meta[t];
     const int new_id = meta->n_nodes, depth = meta->path_len;
-    if (new_id >= P.max_nodes || depth < 1) {  // pool full (or no select before): flag, leave the tree untouched
+    if (new_id >= P.max_nodes || depth < 1) {  // leave the tree untouched
         if (lane == 0) meta->error |= 1;
-        return;
+        return -1;
     }
     const int64_t tbase = (int64_t)t * P.max_nodes;
     write_children<true>(P, tbase + new_id, policy + (int64_t)t * MZ_ACTIONS, ~0ULL, true, nullptr, 0.0, lane);
     const int eb = P.hidden_elem_bytes;
     copy_hidden(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
+    if (lane == 0) {  // link the leaf to its node: parent's child record gets the expanded id
+        const PathRec pr = P.path[tbase + depth - 1];
+        ChildRec *rec = P.stats + (tbase + pr.node) * MZ_ACTIONS + pr.action;
+        rec->nc = (rec->nc & 0xFFFFu) | ((uint32_t)(new_id + 1) << 16);
+        meta->n_nodes = new_id + 1;
+    }
+    return new_id;
+}
 
-    // backpropagate: search_path[k], k = 0..depth (root .. leaf); node k>=1 lives in its parent's
-    // child record (path[k-1].node, path[k-1].action).  Players alternate with depth, so node k has
-    // the leaf's player iff (depth-k) is even.  value_k = value after k times `reward + discount*value`.
-    const float v0 = value[t], disc = (float)cfg.discount;
-    MinMax mm = load_minmax(meta);
+// ---- backpropagate (main.py:180-186) along the stored path ----------------------------------------
+// search_path[k], k = 0..depth (root .. leaf); node k>=1 lives in its parent's child record
+// (path[k-1].node, path[k-1].action).  Players alternate with depth, so node k has the leaf's
+// player iff (depth-k) is even.  value_k = value after k times `reward + discount*value`.
+__device__ __forceinline__ void tree_backup(const Pool &P, const mz_search_cfg &cfg, float v0, int t, int lane) {
+    mz_tree_meta *meta = &P.meta[t];
+    const int depth = meta->path_len;
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    const float disc = (float)cfg.discount;
+    const MinMax mm = load_minmax(meta);
     float vmin = INFINITY, vmax = -INFINITY;
     for (int k0 = 0; k0 <= depth; k0 += 64) {
         const int k = k0 + lane;
@@ -298,9 +312,8 @@ __device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_searc
             } else {
                 const PathRec pr = P.path[tbase + k - 1];
                 ChildRec *rec = P.stats + (tbase + pr.node) * MZ_ACTIONS + pr.action;
-                uint32_t nc = rec->nc + 1u;
+                const uint32_t nc = rec->nc + 1u;
                 const float w = rec->w + sv;
-                if (k == depth) nc |= (uint32_t)(new_id + 1) << 16;  // the leaf is expanded now
                 rec->nc = nc;
                 rec->w = w;
                 nv = w / (float)(nc & 0xFFFFu);
@@ -318,8 +331,14 @@ __device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_searc
         if (mx_lt(mx_t(vmin), mm.lo)) { meta->mm_min = (double)vmin; f |= 1; }
         if (mx_gt(mx_t(vmax), mm.hi)) { meta->mm_max = (double)vmax; f |= 2; }
         meta->mm_flags = f;
-        meta->n_nodes = new_id + 1;
     }
+}
+
+__device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_search_cfg &cfg, const float *value, const float *policy,
+                                                   const char *hidden, int t, int lane) {
+    if (tree_expand(P, policy, hidden, t, lane) < 0) return;
+    __syncthreads();  // lane 0 linked the leaf record that the backup's lane `depth` updates next
+    tree_backup(P, cfg, value[t], t, lane);
 }
 
 __global__ void __launch_bounds__(64) k_select(Pool P, mz_search_cfg cfg, char *net_in) {
@@ -336,6 +355,56 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
     // within the workgroup (one wave) before reading
     __syncthreads();
     tree_select(P, cfg, net_in, blockIdx.x, threadIdx.x);
+}
+
+// ---- single-call entry points for the reference-shaped Python API (muzero_amd/compat.py) ----------
+__global__ void __launch_bounds__(64) k_expand(Pool P, const float *policy, const char *hidden) {
+    tree_expand(P, policy, hidden, blockIdx.x, threadIdx.x);
+}
+__global__ void __launch_bounds__(64) k_backup(Pool P, mz_search_cfg cfg, const float *value) {
+    tree_backup(P, cfg, value[blockIdx.x], blockIdx.x, threadIdx.x);
+}
+// select_child / ucb_score for ONE node per tree: action_out[t] = argmax action (or -1 when the
+// node is not expanded); score_out (nullable) [t][65] doubles, kind_out [t][65] bytes: 0 = Python
+// float, 1 = fp32 tensor, 255 = not a child.
+__global__ void __launch_bounds__(64) k_node_scores(Pool P, mz_search_cfg cfg, const int32_t *node_id, int32_t *action_out,
+                                                    double *score_out, uint8_t *kind_out) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const mz_tree_meta *meta = &P.meta[t];
+    const MinMax mm = load_minmax(meta);
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    const int node = node_id[t];
+    if (node < 0 || node >= meta->n_nodes) {
+        if (lane == 0) action_out[t] = -1;
+        return;
+    }
+    // the parent's visit count: root's own counter, else found in the record that links to `node`
+    uint32_t np = (uint32_t)meta->root_n;
+    if (node != 0) {
+        np = 0;
+        for (int q = 0; q < meta->n_nodes; ++q) {
+            const ChildRec *rq = P.stats + (tbase + q) * MZ_ACTIONS;
+            for (int a = lane; a < MZ_ACTIONS; a += 64) {
+                const uint32_t nc = rq[a].nc;
+                if (nc != NOT_CHILD && (int)(nc >> 16) == node + 1) np = nc & 0xFFFFu;
+            }
+        }
+        np = (uint32_t)wave_max_f32((float)np);
+    }
+    const ChildRec *recs = P.stats + (tbase + node) * MZ_ACTIONS;
+    const ChildRec r = recs[lane], r64 = recs[64];
+    const PbcRec pb = P.pbc[np];
+    const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+    const int a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, cfg.tie_lowest != 0);
+    if (lane == 0) action_out[t] = a;
+    if (score_out) {
+        score_out[(int64_t)t * MZ_ACTIONS + lane] = s.d;
+        kind_out[(int64_t)t * MZ_ACTIONS + lane] = r.nc == NOT_CHILD ? 255 : (s.t ? 1 : 0);
+        if (lane == 0) {
+            score_out[(int64_t)t * MZ_ACTIONS + 64] = s64.d;
+            kind_out[(int64_t)t * MZ_ACTIONS + 64] = r64.nc == NOT_CHILD ? 255 : (s64.t ? 1 : 0);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(64) k_root_stats(Pool P, int32_t *visits, float *root_value, float *wsum, double *prior) {
@@ -445,13 +514,13 @@ extern "C" int mz_pool_init(void *pool, const mz_pool_layout *L, const mz_search
 }
 
 extern "C" int mz_mcts_root_init(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const int8_t *to_play,
-                                 const uint64_t *legal, const float *policy, const double *noise, const void *hidden, int32_t n_trees,
-                                 void *stream) {
+                                 const uint64_t *legal, const uint8_t *pass_ok, const float *policy, const double *noise,
+                                 const void *hidden, int32_t n_trees, void *stream) {
     if (int rc = check_pool("mz_mcts_root_init", pool, L, n_trees)) return rc;
     if (n_trees == 0) return MZ_OK;
     MZ_REQUIRE(cfg && to_play && legal && policy && hidden, "mz_mcts_root_init: null pointer");
-    hipLaunchKernelGGL(k_root_init, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, to_play, legal, policy,
-                       noise, (const char *)hidden);
+    hipLaunchKernelGGL(k_root_init, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, to_play, legal, pass_ok,
+                       policy, noise, (const char *)hidden);
     MZ_LAUNCH_CHECK("k_root_init");
     return MZ_OK;
 }
@@ -506,5 +575,37 @@ extern "C" int mz_select_action(const int32_t *visits, const int32_t *num_moves,
     hipLaunchKernelGGL(k_select_action, dim3(mz_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, visits, num_moves, (int)num_moves_all,
                        u, action, n);
     MZ_LAUNCH_CHECK("k_select_action");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_expand(void *pool, const mz_pool_layout *L, const float *policy, const void *hidden, int32_t n_trees,
+                              void *stream) {
+    if (int rc = check_pool("mz_mcts_expand", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(policy && hidden, "mz_mcts_expand: null pointer");
+    hipLaunchKernelGGL(k_expand, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), policy, (const char *)hidden);
+    MZ_LAUNCH_CHECK("k_expand");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_backup(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const float *value, int32_t n_trees,
+                              void *stream) {
+    if (int rc = check_pool("mz_mcts_backup", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && value, "mz_mcts_backup: null pointer");
+    hipLaunchKernelGGL(k_backup, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value);
+    MZ_LAUNCH_CHECK("k_backup");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_node_scores(const void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const int32_t *node_id,
+                                   int32_t *action, double *score, uint8_t *kind, int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_node_scores", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && node_id && action, "mz_mcts_node_scores: null pointer");
+    MZ_REQUIRE((score == nullptr) == (kind == nullptr), "mz_mcts_node_scores: score and kind go together");
+    hipLaunchKernelGGL(k_node_scores, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, node_id, action, score,
+                       kind);
+    MZ_LAUNCH_CHECK("k_node_scores");
     return MZ_OK;
 }

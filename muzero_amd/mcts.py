@@ -57,11 +57,11 @@ class BatchedMCTS:
     def _args(self):
         return L.dptr(self.pool), C.byref(self.layout), C.byref(self.cfg)
 
-    def root_init(self, to_play, legal, policy, hidden, noise=None):
+    def root_init(self, to_play, legal, policy, hidden, noise=None, pass_ok=None):
         """play_game main.py:75-83: root expansion over legal actions + exploration noise.
         to_play int8 (n,), legal int64 (n,), policy f32 (n,65), hidden (n,8,8,8), noise f64 (n,65) by action."""
         self._check(policy, hidden)
-        L.call("mz_mcts_root_init", *self._args(), L.dptr(to_play), L.dptr(legal), L.dptr(policy), L.dptr(noise),
+        L.call("mz_mcts_root_init", *self._args(), L.dptr(to_play), L.dptr(legal), L.dptr(pass_ok), L.dptr(policy), L.dptr(noise),
                L.dptr(hidden), self.n, L.current_stream())
         self.sims_done = 0
 

@@ -134,26 +134,7 @@ def gen_env():
 # ------------------------------------------------------------------------------------------------
 # MCTS traces
 # ------------------------------------------------------------------------------------------------
-class HashNetwork:
-    """duck-typed stand-in for network.Network (value (1,1), policy (1,65), hidden (1,8,8,8))."""
-
-    def __init__(self, mode="hash"):
-        self.mode = mode
-        self.calls = []  # (parent_h, action_code)
-
-    def _out(self, h):
-        v, p = R.hashnet_outputs(h, self.mode)
-        return (torch.tensor([[v]], dtype=torch.float32), torch.from_numpy(p).unsqueeze(0),
-                torch.from_numpy(R.hashnet_hidden(h)).reshape(1, 8, 8, 8))
-
-    def initial_inference(self, image):
-        return self._out(R.hashnet_image_hash(image.numpy()))
-
-    def recurrent_inference(self, hidden, action):
-        h = R.hashnet_h_from_hidden(hidden.numpy())
-        code = R.hashnet_action_code(action.numpy())
-        self.calls.append((h, code))
-        return self._out(R.hashnet_step(h, code))
+from hashnet_ref import HashNetwork  # noqa: E402  (shared with the compat tests)
 
 
 class RecordingNetwork:
@@ -425,7 +406,15 @@ def gen_game():
                 g2.apply(M.Action(game.action_history[t].index, g2.to_play()))
             u = np.zeros(n, np.float64)
             u[:len(us)] = us  # moves >= 20 are greedy and draw nothing
-            recs.append(dict(S=S, actions=np.array([a.index for a in game.action_history], np.uint8),
+            tgt_idx = [0, 1, 30, 56, 57, 58, 59]
+            tv, tp = [], []
+            for K in (3, 5):
+                for si in tgt_idx:
+                    v_, p_ = game.make_target(si, K)
+                    tv.append(np.array(v_ + [0] * (6 - len(v_)), np.float64))
+                    tp.append(np.array([list(x) for x in p_] + [[0] * 65] * (6 - len(p_)), np.float64))
+            recs.append(dict(S=S, target_index=np.array(tgt_idx, np.int32), target_values=np.stack(tv), target_policies=np.stack(tp),
+                             actions=np.array([a.index for a in game.action_history], np.uint8),
                              rewards=np.array(game.rewards, np.int8), noise=noise, u=u,
                              child_visits=np.array(game.child_visits, np.float64),
                              root_values=np.array([float(v) for v in game.root_values], np.float32),
