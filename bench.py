@@ -77,6 +77,22 @@ def make_roots(n, seed, game0, device):
     return r, hw, hb, idx
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE
+    (doubled, MI355X_MICROARCH.md gfx950 correction) + WRITE_SIZE at this bench's launch shape.
+    rocprofv3 cannot run inside this process, so the number is read from the newest profile; None
+    when no profile is present."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, r, "pmc_summary.json")
+        if os.path.exists(f):
+            rec = json.load(open(f)).get(kernel)
+            if rec and rec.get("hbm_bytes_per_launch"):
+                best = rec["hbm_bytes_per_launch"]
+    return best
+
+
 def event_time_ms(fn, iters):
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
@@ -119,7 +135,8 @@ def bench_env(args, device):
         "env_steps_per_sec_fused_playout": n * 60 / (ms_fused * 1e-3),
         "env_steps_per_sec_step_kernel": n / (ms_step * 1e-3),
         "roofline_env": {"kernel": "k_env_step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "bytes_per_step": ENV_BYTES_PER_STEP,
+                         "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step"), "bytes_per_step": ENV_BYTES_PER_STEP,
+                         "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP,
                          "us_per_launch": ms_step * 1e3},
     }
 
@@ -228,38 +245,46 @@ def main():
         # ---- roofline of the dominant hand-written kernel: k_backup_select, HIP-event timed on the launch stream
         from muzero_amd import _lib as L
         from muzero_amd import mcts as MC
-        v, p, h = net.recurrent(eng.mcts.net_in)
-        h = h.reshape(n, 8, 8, 8).contiguous()
         noise = eng.dirichlet_noise(roots.legal)
         v0, p0, h0 = net.initial(image)
+        h0 = h0.reshape(n, 8, 8, 8).contiguous()
+        # pass 1: one real search, recording the network outputs of every simulation and the path depths
+        eng.mcts.root_init(roots.to_play, roots.legal, p0, h0, noise)
+        eng.mcts.select()
+        rec, depth_sum = [], 0.0
+        for s in range(S - 1):
+            v, p, h = net.recurrent(eng.mcts.net_in)
+            rec.append((v.clone(), p.clone(), h.reshape(n, 8, 8, 8).clone()))
+            depth_sum += float(eng.mcts.meta()[:, MC.META_PATH_LEN].float().mean())
+            eng.mcts.backup_select(*rec[-1])
+        # pass 2: replay the same search with the kernel launched back to back (identical trees,
+        # nothing but k_backup_select between the two events on the launch stream)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tot_ms, depth_sum, launches = 0.0, 0.0, 0
-        for rep in range(3):
-            eng.mcts.root_init(roots.to_play, roots.legal, p0, h0.reshape(n, 8, 8, 8).contiguous(), noise)
+        tot_ms, launches = 0.0, 0
+        for rep in range(5):
+            eng.mcts.root_init(roots.to_play, roots.legal, p0, h0, noise)
             eng.mcts.select()
+            torch.cuda.synchronize()
+            start.record()
             for s in range(S - 1):
-                # feed real network outputs so the trees grow as in the timed region; time only the kernel
-                v, p, h = net.recurrent(eng.mcts.net_in)
-                h = h.reshape(n, 8, 8, 8).contiguous()
-                depth_sum += float(eng.mcts.meta()[:, MC.META_PATH_LEN].float().mean()) if rep == 0 else 0.0
-                start.record()
-                eng.mcts.backup_select(v, p, h)
-                end.record()
-                end.synchronize()
-                tot_ms += start.elapsed_time(end)
-                launches += 1
-            eng.mcts.sims_done = 0
+                eng.mcts.backup_select(*rec[s])
+            end.record()
+            end.synchronize()
+            tot_ms += start.elapsed_time(end)
+            launches += S - 1
+        del rec
         d = depth_sum / (S - 1)
         eb = 2 if dtype != torch.float32 else 4
-        # algorithmic bytes per simulation (DESIGN.md): descent d x 65 x 16 B; expansion 260+4 B in, 65 x 16 B out;
+        # algorithmic bytes per simulation (DESIGN.md 4): descent d x 65 x 16 B; expansion 260+4 B in, 65 x 16 B out;
         # backup (d+1) x 16 B r/w; path/leaf records 16 B; hidden state: copy-in 2 x 512 x eb, gather 512 x eb in + 640 x eb out
         tree_bytes = 1040.0 * d + 1040 + 264 + 16.0 * (d + 1) + 16
         hid_bytes = (2 * 512 + 512 + 640) * eb
         us = tot_ms / launches * 1e3
         gbps = n * (tree_bytes + hid_bytes) / (us * 1e-6) / 1e9
         out["roofline"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": us, "mean_depth": d,
-                           "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes, "trees_per_launch": n}
+                           "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "us_per_launch": us,
+                           "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
+                           "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes)}
         # ---- inference share: the same S-1 recurrent calls alone
         ms_net = event_time_ms(lambda: net.recurrent(eng.mcts.net_in), 20)
         tf = n * NET_MFLOP * 1e6 / (ms_net * 1e-3) / 1e12
