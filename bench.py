@@ -205,7 +205,9 @@ def main():
     net = InferenceEngine(Network(), args.trees, dtype)
     n, S = args.trees, args.sims
     eng = SelfPlayEngine(n, net, num_simulations=S, device=device, use_graph=not args.no_graph, seed=1261 + rank)
-    roots, hw, hb, idx = make_roots(n, 1261, rank * n, device)
+    from muzero_amd.shard import game_block, max_over_ranks
+    game0, _ = game_block(n * world, rank, world)  # weak scaling: n trees per GPU, ids partitioned by rank
+    roots, hw, hb, idx = make_roots(n, 1261, game0, device)
     eng.env = roots
     image = make_image(hw, hb, idx, n, dtype)
 
@@ -226,10 +228,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, device)
     sims = args.steps * n * S * world
     out = {
         "metric": "mcts_simulations_per_sec", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
