@@ -5,54 +5,84 @@
 // row*8+col.  Move generation and flipping are Kogge-Stone style directional fills: a run of
 // opponent discs adjacent to the mover's disc (movegen) or to the placed disc (flip) is grown by
 // shift-and-mask in log steps (1,1,2,2 -> up to 6 discs, the longest run an 8-wide board allows).
-// Everything is integer VALU work on registers; HBM traffic is the SoA state itself.
+// Everything is 32-bit integer VALU work on registers; HBM traffic is the SoA state itself.
 #include "common.h"
 
 namespace {
 
+// Instruction selection is driven by measured gfx950 issue costs (tools/valu_rate.hip, r01):
+//   v_and/v_or_b32, v_bitop3_b32            ~2.4 cycles per wave64 instruction (full rate)
+//   v_lsh{l,r}rev_b32, v_lsh{l,r}rev_b64,
+//   v_alignbit_b32, v_and_or_b32            ~4.2 cycles (half rate)
+// so a 64-bit shift must stay ONE v_lsh*rev_b64 (hipcc otherwise splits it into a 32-bit shift plus
+// v_alignbit, twice the cost: hence the asm wrappers) and each mask-and-merge of a fill step is one
+// v_bitop3_b32 per 32-bit half instead of v_and + v_or or the half-rate v_and_or.
+template <int D> __device__ __forceinline__ uint64_t shl(uint64_t x) {
+    uint64_t r;
+    asm("v_lshlrev_b64 %0, %1, %2" : "=v"(r) : "i"(D), "v"(x));
+    return r;
+}
+template <int D> __device__ __forceinline__ uint64_t shr(uint64_t x) {
+    uint64_t r;
+    asm("v_lshrrev_b64 %0, %1, %2" : "=v"(r) : "i"(D), "v"(x));
+    return r;
+}
+// (a & b) | c  -- truth table 0xEA for inputs a=0xF0, b=0xCC, c=0xAA
+__device__ __forceinline__ uint64_t and_or(uint64_t a, uint64_t b, uint64_t c) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xEA);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xEA);
+    return ((uint64_t)hi << 32) | lo;
+}
+// a | b | c  -- truth table 0xFE
+__device__ __forceinline__ uint64_t or3(uint64_t a, uint64_t b, uint64_t c) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xFE);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xFE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 constexpr uint64_t INNER = 0x7E7E7E7E7E7E7E7EULL;  // columns 1..6: horizontal/diagonal runs never contain an edge file
 
-// mover discs P, opponent run mask M, direction +D (<<) and -D (>>): empty-or-not squares that end a run
+// mover discs P, opponent run mask M, direction +D (<<) and -D (>>): squares that end a run
 template <int D>
 __device__ __forceinline__ uint64_t moves_dir(uint64_t P, uint64_t M) {
-    uint64_t fl = M & (P << D), fr = M & (P >> D);
-    fl |= M & (fl << D);
-    fr |= M & (fr >> D);
-    const uint64_t ml = M & (M << D), mr = ml >> D;
-    fl |= ml & (fl << (2 * D));
-    fr |= mr & (fr >> (2 * D));
-    fl |= ml & (fl << (2 * D));
-    fr |= mr & (fr >> (2 * D));
-    return (fl << D) | (fr >> D);
+    uint64_t fl = M & shl<D>(P), fr = M & shr<D>(P);
+    fl = and_or(M, shl<D>(fl), fl);
+    fr = and_or(M, shr<D>(fr), fr);
+    const uint64_t ml = M & shl<D>(M), mr = shr<D>(ml);
+    fl = and_or(ml, shl<2 * D>(fl), fl);
+    fr = and_or(mr, shr<2 * D>(fr), fr);
+    fl = and_or(ml, shl<2 * D>(fl), fl);
+    fr = and_or(mr, shr<2 * D>(fr), fr);
+    return shl<D>(fl) | shr<D>(fr);
 }
 
 // reversi.py:81-126: legal placements of the side owning `own`
 __device__ __forceinline__ uint64_t legal_moves(uint64_t own, uint64_t opp) {
     const uint64_t mo = opp & INNER;
-    uint64_t mv = moves_dir<1>(own, mo) | moves_dir<7>(own, mo) | moves_dir<9>(own, mo) | moves_dir<8>(own, opp);
+    const uint64_t mv = or3(moves_dir<1>(own, mo), moves_dir<7>(own, mo), moves_dir<9>(own, mo)) | moves_dir<8>(own, opp);
     return mv & ~(own | opp);
 }
 
 // discs flipped along +-D by placing the single bit m (reversi.py:149-162)
 template <int D>
 __device__ __forceinline__ uint64_t flips_dir(uint64_t m, uint64_t P, uint64_t M) {
-    uint64_t fl = M & (m << D), fr = M & (m >> D);
-    fl |= M & (fl << D);
-    fr |= M & (fr >> D);
-    const uint64_t ml = M & (M << D), mr = ml >> D;
-    fl |= ml & (fl << (2 * D));
-    fr |= mr & (fr >> (2 * D));
-    fl |= ml & (fl << (2 * D));
-    fr |= mr & (fr >> (2 * D));
+    uint64_t fl = M & shl<D>(m), fr = M & shr<D>(m);
+    fl = and_or(M, shl<D>(fl), fl);
+    fr = and_or(M, shr<D>(fr), fr);
+    const uint64_t ml = M & shl<D>(M), mr = shr<D>(ml);
+    fl = and_or(ml, shl<2 * D>(fl), fl);
+    fr = and_or(mr, shr<2 * D>(fr), fr);
+    fl = and_or(ml, shl<2 * D>(fl), fl);
+    fr = and_or(mr, shr<2 * D>(fr), fr);
     // the run is captured iff the square just past its end holds a mover disc
-    uint64_t r = (P & (fl << D)) ? fl : 0ULL;
-    r |= (P & (fr >> D)) ? fr : 0ULL;
+    uint64_t r = (P & shl<D>(fl)) ? fl : 0ULL;
+    r |= (P & shr<D>(fr)) ? fr : 0ULL;
     return r;
 }
 
 __device__ __forceinline__ uint64_t flips_for(uint64_t m, uint64_t own, uint64_t opp) {
     const uint64_t mo = opp & INNER;
-    return flips_dir<1>(m, own, mo) | flips_dir<7>(m, own, mo) | flips_dir<9>(m, own, mo) | flips_dir<8>(m, own, opp);
+    return or3(flips_dir<1>(m, own, mo), flips_dir<7>(m, own, mo), flips_dir<9>(m, own, mo)) | flips_dir<8>(m, own, opp);
 }
 
 struct EnvState {
@@ -155,7 +185,8 @@ __global__ void __launch_bounds__(256) k_env_legal_mask(const uint64_t *black, c
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint64_t b = black[i], w = white[i];
-    legal[i] = to_play[i] == 1 ? legal_moves(w, b) : legal_moves(b, w);
+    const bool white_moves = to_play[i] == 1;
+    legal[i] = legal_moves(white_moves ? w : b, white_moves ? b : w);
 }
 
 __global__ void __launch_bounds__(256) k_env_step(uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *steps,
