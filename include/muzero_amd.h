@@ -219,6 +219,17 @@ int mz_mcts_root_stats(const void *pool, const mz_pool_layout *layout, int32_t *
 int mz_select_action(const int32_t *visits, const int32_t *num_moves, int32_t num_moves_all, const double *u,
                      uint8_t *action, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Inference epilogue (network.py:35-47, 54-68, 118-128: what surrounds every nn.Conv2d)
+ * ---------------------------------------------------------------------------------------- */
+
+/* In place over a channels-last activation y (n_elems elements, `channels` innermost):
+ *   y = act(y + bias[c] (+ residual)),  act = ReLU if relu != 0
+ * i.e. the conv bias, the ResidualBlock skip add (network.py:46-47) and nn.ReLU in one pass instead
+ * of PyTorch's three.  bias / residual nullable; fp32 arithmetic, one rounding to dtype. */
+int mz_bias_act_nhwc(void *y, const void *bias, const void *residual, int64_t n_elems, int32_t channels,
+                     int32_t dtype, int32_t relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

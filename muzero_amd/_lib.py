@@ -62,6 +62,7 @@ SIGNATURES = {
     "mz_mcts_node_scores": [_p, _LP, _CP, _p, _p, _p, _p, _i32, _p],
     "mz_mcts_root_stats": [_p, _LP, _p, _p, _p, _p, _i32, _p],
     "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
+    "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

@@ -124,13 +124,17 @@ class Network(nn.Module):
 
 
 class InferenceEngine:
-    """Serves a Network to the batched search: fixed batch size, fixed buffers, optional hipGraph.
+    """Serves a Network to the batched search: fixed batch size, fixed dtype / memory format.
 
     ``initial(image)`` and ``recurrent(x10)`` return (value f32 (B,), policy f32 (B,65), hidden
     (B,8,8,8) of ``dtype``, contiguous NCHW) -- exactly what the tree kernels consume.
+
+    ``fused=True`` (default, needs channels_last) keeps MIOpen for the convolutions but replaces the
+    bias add / residual add / ReLU passes PyTorch runs after each of them by ONE in-place HIP pass
+    (``mz_bias_act_nhwc``): same arithmetic in fp32, one rounding instead of up to three.
     """
 
-    def __init__(self, network, batch, dtype=torch.float32, channels_last=True, device="cuda"):
+    def __init__(self, network, batch, dtype=torch.float32, channels_last=True, device="cuda", fused=True):
         self.device = torch.device(device)
         self.batch = int(batch)
         self.dtype = dtype
@@ -142,16 +146,53 @@ class InferenceEngine:
             self.net = self.net.to(memory_format=torch.channels_last)
         for p in self.net.parameters():
             p.requires_grad_(False)
+        self.fused = bool(fused and channels_last)
+        if self.fused:
+            from . import _lib
+            self._L = _lib
+            self._dt = {torch.float32: _lib.MZ_F32, torch.bfloat16: _lib.MZ_BF16, torch.float16: _lib.MZ_F16}[dtype]
 
-    def _finish(self, out):
-        value, policy, hidden = out
+    # ---- fused tower: conv (MIOpen, no bias) + one epilogue pass ---------------------------------
+    def _epi(self, y, bias, residual=None):
+        L = self._L
+        if not y.is_contiguous(memory_format=torch.channels_last) or (residual is not None and not residual.is_contiguous(memory_format=torch.channels_last)):
+            raise L.MzError("fused inference needs channels_last activations")
+        import ctypes as C
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        L.call("mz_bias_act_nhwc", ptr(y), ptr(bias), ptr(residual), y.numel(), y.shape[1], self._dt, 1, L.current_stream())
+        return y
+
+    def _conv(self, x, conv, residual=None):
+        return self._epi(F.conv2d(x, conv.weight, None, 1, 1), conv.bias, residual)
+
+    def _tower(self, x, first, blocks, last):
+        y = self._conv(x, first)
+        for blk in blocks:
+            t = self._conv(y, blk.block[0])
+            y = self._conv(t, blk.block[2], residual=y)   # relu(x + block(x)), network.py:46-47
+        return self._conv(y, last)
+
+    def _hidden_initial(self, image):
+        r = self.net.representation
+        if not self.fused:
+            return r(image)
+        return self._tower(image, r.conv1[0], list(r.conv2), r.conv3[0])
+
+    def _hidden_recurrent(self, x10):
+        d = self.net.dynamics.conv
+        if not self.fused:
+            return d(x10)
+        return self._tower(x10, d[0], [d[2], d[3], d[4]], d[5])
+
+    def _finish(self, hidden):
+        policy, value = self.net.prediction(hidden)
         return (value.float().reshape(-1).contiguous(), policy.float().contiguous(),
                 hidden.contiguous(memory_format=torch.contiguous_format))
 
     @torch.no_grad()
     def initial(self, image):
-        return self._finish(self.net.initial_inference(image.to(self.dtype).contiguous(memory_format=self.mf)))
+        return self._finish(self._hidden_initial(image.to(self.dtype).contiguous(memory_format=self.mf)))
 
     @torch.no_grad()
     def recurrent(self, x10):
-        return self._finish(self.net.recurrent_inference_packed(x10.contiguous(memory_format=self.mf)))
+        return self._finish(self._hidden_recurrent(x10.contiguous(memory_format=self.mf)))
