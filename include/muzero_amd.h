@@ -220,6 +220,45 @@ int mz_select_action(const int32_t *visits, const int32_t *num_moves, int32_t nu
                      uint8_t *action, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Replay buffer + training targets (utilities.py:46-109 ReplayBuffer; reversi.py:314-341 make_target)
+ * ---------------------------------------------------------------------------------------- */
+
+/* A window of `window` finished games, game-major, in caller-owned device arrays (host struct of
+ * device pointers).  Slot order is the caller's business (the Python ReplayBuffer keeps the FIFO of
+ * utilities.py:56-63).  The mover of step t is BLACK for even t: Environment switches the player on
+ * every step (reversi.py:137,176) and BLACK starts (reversi.py:54). */
+typedef struct mz_replay {
+    uint64_t *white;    /* [window][max_moves+1] Game.state_history, plane 0 (WHITE) as bitboards */
+    uint64_t *black;    /* [window][max_moves+1] plane 1 (BLACK) */
+    uint8_t *actions;   /* [window][max_moves]   Game.action_history indices */
+    int8_t *rewards;    /* [window][max_moves]   Game.rewards */
+    float *policy;      /* [window][max_moves][65] Game.child_visits = N_a / sum N computed in double
+                           (reversi.py:292-298), rounded once to fp32 (torch.FloatTensor, main.py:236) */
+    float *root_values; /* [window][max_moves]   Game.root_values */
+    int32_t *length;    /* [window]              len(action_history) */
+    int32_t window, max_moves;
+} mz_replay;
+
+/* ReplayBuffer.save_game (utilities.py:56-63) for n games at once: game i of a step-major batch of
+ * trajectories (the layout the self-play engine records: hist_* [t * stride + i], t = 0..max_moves;
+ * actions/rewards/root_values [t * stride + i]; visits [(t * stride + i) * 65 + a], -1 = not a root
+ * child) is written to slot (slot0 + i) mod window.  length: per-game (nullable) else length_all.
+ * Game.store_search_statistics' normalisation (reversi.py:292-299) happens here. */
+int mz_replay_save(const mz_replay *rb, int32_t slot0, const uint64_t *hist_white, const uint64_t *hist_black,
+                   const uint8_t *actions, const int8_t *rewards, const int32_t *visits, const float *root_values,
+                   const int32_t *length, int32_t length_all, int64_t stride, int32_t n, void *stream);
+
+/* ReplayBuffer.sample_batch (utilities.py:72-99) for `batch` already-drawn (slot, position) pairs
+ * (the draws stay with the caller: random.sample / random.randint, utilities.py:76,104), K =
+ * num_unroll_steps, position + K <= length.  One wavefront per sample.  Outputs, all fp32:
+ *   image           (batch,9,8,8)    Game.make_image(position)                   utilities.py:88
+ *   actions         (K,batch,2,8,8)  Action.encode of the K real moves           utilities.py:89,95
+ *   target_values   (K+1,batch)      Game.make_target values                     reversi.py:331-338
+ *   target_policies (K+1,batch,65)   Game.make_target policies (zeros past end)  reversi.py:335,339 */
+int mz_replay_sample_batch(const mz_replay *rb, const int32_t *slot, const int32_t *pos, int32_t batch, int32_t K,
+                           float *image, float *actions, float *target_values, float *target_policies, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Inference epilogue (network.py:35-47, 54-68, 118-128: what surrounds every nn.Conv2d)
  * ---------------------------------------------------------------------------------------- */
 

@@ -32,6 +32,13 @@ class PoolLayout(C.Structure):
                 ("hidden_elem_bytes", C.c_int32)]
 
 
+class Replay(C.Structure):
+    """mz_replay -- device arrays of the replay window (host struct of device pointers)"""
+    _fields_ = [("white", C.c_void_p), ("black", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p),
+                ("policy", C.c_void_p), ("root_values", C.c_void_p), ("length", C.c_void_p),
+                ("window", C.c_int32), ("max_moves", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "muzero_amd: %s is missing. Build it with `make -C muzero_amd/csrc` (or "
@@ -40,7 +47,7 @@ if not os.path.exists(LIB_PATH):
 lib = C.CDLL(LIB_PATH)
 
 _p, _i32, _i64, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
-_LP, _CP = C.POINTER(PoolLayout), C.POINTER(SearchCfg)
+_LP, _CP, _RP = C.POINTER(PoolLayout), C.POINTER(SearchCfg), C.POINTER(Replay)
 
 # name -> argtypes; every symbol include/muzero_amd.h declares (tests check the export list)
 SIGNATURES = {
@@ -63,6 +70,8 @@ SIGNATURES = {
     "mz_mcts_root_stats": [_p, _LP, _p, _p, _p, _p, _i32, _p],
     "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
     "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
+    "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

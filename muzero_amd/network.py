@@ -152,6 +152,18 @@ class InferenceEngine:
             self._L = _lib
             self._dt = {torch.float32: _lib.MZ_F32, torch.bfloat16: _lib.MZ_BF16, torch.float16: _lib.MZ_F16}[dtype]
 
+    @torch.no_grad()
+    def load_weights(self, state_dict):
+        """publish new weights (SharedStorage.save_network -> run_selfplay's load_state_dict,
+        main.py:60-61,216-221) IN PLACE: dtype/memory-format casts happen in copy_, and the parameter
+        storage a captured hipGraph points at stays where it is."""
+        own = self.net.state_dict()
+        missing = set(own) ^ set(state_dict)
+        if missing:
+            raise KeyError("state_dict mismatch: %s" % sorted(missing))
+        for k, t in own.items():
+            t.copy_(state_dict[k])
+
     # ---- fused tower: conv (MIOpen, no bias) + one epilogue pass ---------------------------------
     def _epi(self, y, bias, residual=None):
         L = self._L

@@ -1,0 +1,197 @@
+"""Training side of the loop: reference main.py:201-272 (train_network / update_weights), the
+checkpoint format of main.py:223-224 plus a resume the reference lacks, and the one collective of
+the whole system -- a single flat-bucket gradient all-reduce (RCCL over xGMI on the GPUs, gloo in
+the CPU tests).
+
+The networks and the optimiser stay PyTorch (north_star); what is build-specific:
+
+  * ``FlatGradBucket``: every parameter's ``.grad`` is a view into ONE contiguous fp32 buffer
+    (1,836,526 elements = 7.35 MB), so data-parallel training costs exactly one all-reduce per step.
+    On an 8-GPU xGMI ring that is latency-dominated, hence one bucket, not many.
+  * ``update_weights`` keeps the reference's signature and loss, accepts the device tensors
+    ``muzero_amd.replay.ReplayBuffer.sample_batch`` returns (or the reference's numpy arrays), and
+    returns the two loss terms instead of only printing them.
+  * every rank applies the same averaged gradient to the same weights, so the replicas stay
+    identical without a weight broadcast; ``broadcast_weights`` exists for (re)joining ranks / resume.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+
+from . import config
+
+
+def _dist_on(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+class FlatGradBucket:
+    """all gradients of `params` as views of one contiguous buffer -> one all-reduce per step"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        p0 = self.params[0]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=p0.dtype, device=p0.device)
+        self.attach()
+
+    def attach(self):
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
+    def zero(self):
+        """optimizer.zero_grad() that keeps the views (set_to_none would detach them)"""
+        self.flat.zero_()
+        if any(p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or
+               p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size() for p in self.params):
+            self.attach()
+
+    def all_reduce_mean(self, group=None):
+        """average over the data-parallel ranks: each rank's loss is a mean over ITS batch, so the
+        mean of the gradients is the gradient of the mean over the global batch (equal shard sizes)"""
+        if not _dist_on(group):
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(dist.get_world_size(group))
+
+
+def make_optimizer(network):
+    """train_network's optimiser (main.py:206): SGD lr 1e-3, momentum config.momentum and -- a quirk of
+    the reference kept on purpose -- weight_decay = config.lr_decay_rate (0.1)"""
+    return optim.SGD(network.parameters(), lr=0.001, weight_decay=config.lr_decay_rate, momentum=config.momentum)
+
+
+def muzero_loss(network, batch):
+    """main.py:239-265: K-step unrolled loss.  Returns (p_loss, v_loss) tensors.
+    p_loss = mean over (B, K+1) of -sum_a pi log p ; v_loss = mean over B of sum_k (z - v)^2."""
+    dev = next(network.parameters()).device
+    image, actions, target_values, target_policies = (torch.as_tensor(x, dtype=torch.float32).to(dev) for x in batch)
+    value, policy, hidden_state = network.initial_inference(image)
+    p_value, p_policy = [value], [policy]
+    for action in actions:
+        value, policy, hidden_state = network.recurrent_inference(hidden_state, action)
+        p_value.append(value)
+        p_policy.append(policy)
+    p_value = torch.stack(p_value).squeeze(-1)      # (K+1, B); the reference's bare .squeeze() also drops B == 1
+    p_policy = torch.stack(p_policy)                # (K+1, B, 65)
+    target_policies = target_policies.transpose(0, 1)
+    p_policy = p_policy.transpose(0, 1)
+    target_values = target_values.transpose(0, 1)
+    p_value = p_value.transpose(0, 1)
+    p_loss = torch.mean(torch.sum(-target_policies * torch.log(p_policy), dim=2))
+    v_loss = torch.mean(torch.sum((target_values - p_value) ** 2, dim=1))
+    return p_loss, v_loss
+
+
+def update_weights(optimizer, network, batch, bucket=None, group=None):
+    """main.py:230-272.  With `bucket` (FlatGradBucket over network.parameters()) the gradients are
+    averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step."""
+    if bucket is not None:
+        bucket.zero()
+    else:
+        optimizer.zero_grad()
+    p_loss, v_loss = muzero_loss(network, batch)
+    (p_loss + v_loss).backward()
+    if bucket is not None:
+        bucket.all_reduce_mean(group)
+    elif _dist_on(group):
+        raise RuntimeError("data-parallel update_weights needs a FlatGradBucket")
+    optimizer.step()
+    if network.steps % 10 == 0:
+        print('step {}: p_loss {:.4f} v_loss {:.4f}'.format(network.steps, float(p_loss.detach()), float(v_loss.detach())))
+    network.steps += 1
+    return p_loss.detach(), v_loss.detach()
+
+
+class SharedStorage:
+    """network.py:169-178 without Ray: holds the latest published weights in-process"""
+
+    def __init__(self, network_id=None):
+        self.network_id = network_id
+
+    def get_network(self):
+        return self.network_id
+
+    def save_network(self, network_id):
+        self.network_id = network_id
+
+
+def broadcast_weights(network, src=0, group=None):
+    """one flat broadcast of all parameters and buffers from `src` (joining ranks, resume)"""
+    if not _dist_on(group):
+        return
+    tensors = [t.data for t in list(network.parameters()) + list(network.buffers())]
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    o = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[o:o + n].view_as(t))
+        o += n
+
+
+# ---- checkpoints: main.py:223-224 format, plus resume ----------------------------------------------
+def checkpoint_path(step, directory="./models"):
+    return os.path.join(directory, "{}model.pth".format(step))  # main.py:224
+
+
+def save_checkpoint(network, step, directory="./models", optimizer=None):
+    """the reference's file: torch.save(network.state_dict()) under ./models/{step}model.pth, loadable
+    by its test.py:247-250.  With `optimizer`, a sidecar {step}train.pth carries what a resume needs."""
+    os.makedirs(directory, exist_ok=True)
+    path = checkpoint_path(step, directory)
+    torch.save({k: v.detach().cpu() for k, v in network.state_dict().items()}, path)
+    if optimizer is not None:
+        torch.save({"optimizer": optimizer.state_dict(), "steps": int(network.steps)}, os.path.join(directory, "{}train.pth".format(step)))
+    return path
+
+
+def load_checkpoint(network, path, optimizer=None):
+    """load a reference-format checkpoint (weights_only: nothing in the file is executed); resume the
+    optimiser/step counter from the sidecar when it exists"""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    network.load_state_dict(sd)
+    side = path.replace("model.pth", "train.pth")
+    if os.path.exists(side):
+        st = torch.load(side, map_location="cpu", weights_only=True)
+        network.steps = int(st["steps"])
+        if optimizer is not None:
+            optimizer.load_state_dict(st["optimizer"])
+    return network
+
+
+def train_network(network, optimizer, storage, replay_buffer, training_steps=None, device=None, group=None,
+                  checkpoint_dir="./models", sleep=None, on_publish=None):
+    """main.py:201-227: sample a batch, update, publish the weights every config.checkpoint_interval
+    steps, save every 1000 steps.  `optimizer` is replaced exactly as the reference does (main.py:206).
+    `sleep` defaults to 0 (the reference sleeps config.training_interval = 0.5 s per step to let its CPU
+    actors keep up; pass it to reproduce that pacing).  Returns the list of (p_loss, v_loss)."""
+    network.train()
+    if device is not None:
+        network.to(device)
+    optimizer = make_optimizer(network)
+    bucket = FlatGradBucket(network.parameters())
+    print('start training')
+    losses = []
+    steps = int(config.training_steps if training_steps is None else training_steps)
+    for i in range(1, steps + 1):
+        batch = replay_buffer.sample_batch(config.num_unroll_steps)
+        losses.append(update_weights(optimizer, network, batch, bucket, group))
+        if i % config.checkpoint_interval == 0:
+            state_dict = network.state_dict()
+            if storage is not None:
+                storage.save_network(state_dict)
+            if on_publish is not None:
+                on_publish(state_dict)
+        if i % 1000 == 0 and (not _dist_on(group) or dist.get_rank(group) == 0):
+            save_checkpoint(network, i, checkpoint_dir, optimizer)
+        if sleep:
+            time.sleep(sleep)
+    return losses

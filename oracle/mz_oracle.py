@@ -68,6 +68,7 @@ def lib():
         L.mzo_search_hashnet.argtypes = [p, C.c_int, u64, C.c_int, p, i64, C.c_int, C.c_int, p, p, p]
         L.mzo_play_game_hashnet.restype = C.c_int
         L.mzo_play_game_hashnet.argtypes = [C.c_int, C.c_int] + [p] * 8
+        L.mzo_replay_sample.argtypes = [p] * 5 + [C.c_int] * 3 + [p] * 4
         _lib = L
     return _lib
 
@@ -225,3 +226,35 @@ def play_game_hashnet(S, mode, noise, u):
     n = lib().mzo_play_game_hashnet(S, mode, ptr(noise), ptr(u), ptr(actions), ptr(rewards), ptr(visits),
                                     ptr(root_values), ptr(hw), ptr(hb))
     return n, actions, rewards, visits, root_values, hw, hb
+
+
+# ---------------------------------------------------------------------------------------------
+# replay buffer batch (utilities.py:72-99) / make_target (reversi.py:314-341)
+# ---------------------------------------------------------------------------------------------
+def replay_sample(hist_white, hist_black, actions, rewards, visits, length, pos, K):
+    """one (game, position) -> (image (9,8,8), action planes (K,2,8,8), target values (K+1,),
+    target policies (K+1,65)), all float32"""
+    hw = np.ascontiguousarray(hist_white, np.uint64)
+    hb = np.ascontiguousarray(hist_black, np.uint64)
+    actions = np.ascontiguousarray(actions, np.uint8)
+    rewards = np.ascontiguousarray(rewards, np.int8)
+    visits = np.ascontiguousarray(visits, np.int32)
+    image = np.zeros((9, 8, 8), np.float32)
+    planes = np.zeros((K, 2, 8, 8), np.float32)
+    tv = np.zeros(K + 1, np.float32)
+    tp = np.zeros((K + 1, 65), np.float32)
+    lib().mzo_replay_sample(ptr(hw), ptr(hb), ptr(actions), ptr(rewards), ptr(visits), int(length), int(pos), int(K),
+                            ptr(image), ptr(planes), ptr(tv), ptr(tp))
+    return image, planes, tv, tp
+
+
+def replay_batch(games, picks, K):
+    """utilities.py:83-99: games = list of dicts (hist_white, hist_black, actions, rewards, visits, length); picks = [(game
+    index, position)] -> (image (B,9,8,8), actions (K,B,2,8,8), target_values (K+1,B), target_policies (K+1,B,65))"""
+    outs = [replay_sample(g["hist_white"], g["hist_black"], g["actions"], g["rewards"], g["visits"], g["length"], pos, K)
+            for g, pos in ((games[i], pos) for i, pos in picks)]
+    image = np.stack([o[0] for o in outs], 0)
+    acts = np.stack([o[1] for o in outs], 0).swapaxes(0, 1)
+    tv = np.stack([o[2] for o in outs], 0).swapaxes(0, 1)
+    tp = np.stack([o[3] for o in outs], 0).swapaxes(0, 1)
+    return image, np.ascontiguousarray(acts), np.ascontiguousarray(tv), np.ascontiguousarray(tp)

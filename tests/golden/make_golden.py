@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the committed golden fixtures by IMPORTING the reference (this container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|all]
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -433,6 +433,151 @@ def gen_game():
     np.savez_compressed(os.path.join(HERE, "selfplay_games.npz"), **out)
 
 
+
+# ------------------------------------------------------------------------------------------------
+# replay buffer (utilities.py:46-109) + update_weights (main.py:230-272)
+# ------------------------------------------------------------------------------------------------
+def _obs_bits(obs):
+    w = b = 0
+    fw, fb = obs[0].reshape(-1), obs[1].reshape(-1)
+    for i in range(64):
+        if fw[i]:
+            w |= 1 << i
+        if fb[i]:
+            b |= 1 << i
+    return w, b
+
+
+def gen_replay():
+    """reference ReplayBuffer filled with main.play_game games (HashNet), FIFO eviction included, then
+    sample_batch under a recorded `random` stream; then reference update_weights on those batches."""
+    import random
+    import utilities as U
+    orig_legal = M.Game.legal_actions
+    M.Game.legal_actions = lambda self: sorted(self.environment.legal_actions, key=lambda a: a.index)
+    orig_store = M.Game.store_search_statistics
+    raw = {}
+
+    def rec_store(self, root):
+        v = np.full(65, -1, np.int32)
+        for a, c in root.children.items():
+            v[a] = c.visit_count
+        raw.setdefault(id(self), []).append(v)
+        return orig_store(self, root)
+
+    M.Game.store_search_statistics = rec_store
+    out = {}
+    try:
+        U.config.window_size, U.config.batch_size = 6, 4
+        rb = U.ReplayBuffer()
+        games = []
+        plan = [(6, 60), (6, 60), (6, 9), (8, 60), (6, 60), (6, 14), (8, 60), (6, 60)]  # (S, max_moves): 8 games into a window of 6
+        for gi, (S, mm) in enumerate(plan):
+            M.config.num_simulations, M.config.max_moves = S, mm
+            np.random.seed(300 + gi)
+            g = M.play_game(HashNetwork("hash"))
+            games.append(g)
+            rb.save_game(g)
+            assert rb.ready() == (gi + 1 >= 4)
+        M.config.num_simulations, M.config.max_moves = 60, 60
+        assert rb.buffer_size == 6 and rb.buffer[0] is games[2]
+        out["count"] = np.int64(rb.count())
+        assert rb.count() == 0
+        n = len(games)
+        L = np.array([len(g.action_history) for g in games], np.int32)
+        HW = np.zeros((n, 61), np.uint64); HB = np.zeros((n, 61), np.uint64)
+        A = np.zeros((n, 60), np.uint8); RW = np.zeros((n, 60), np.int8)
+        V = np.full((n, 60, 65), -1, np.int32); RV = np.zeros((n, 60), np.float32)
+        for i, g in enumerate(games):
+            for t, obs in enumerate(g.state_history):
+                HW[i, t], HB[i, t] = _obs_bits(obs)
+            A[i, :L[i]] = [a.index for a in g.action_history]
+            # the mover of step t is BLACK for even t (the build derives it from parity)
+            assert all((a.player is M.Player.BLACK) == (t % 2 == 0) for t, a in enumerate(g.action_history))
+            RW[i, :L[i]] = g.rewards
+            V[i, :L[i]] = np.stack(raw[id(g)])
+            RV[i, :L[i]] = [float(v) for v in g.root_values]
+        out.update(length=L, hist_white=HW, hist_black=HB, actions=A, rewards=RW, visits=V, root_values=RV,
+                   window_size=np.int32(6), batch_size=np.int32(4), evicted=np.int32(2))
+        print("replay: lengths", L.tolist(), "last rewards", [int(g.rewards[-1]) for g in games])
+        # sample_batch with the `random` draws recorded: game_idxes (list positions, 0 = oldest) and positions
+        orig_sample, orig_randint = random.sample, random.randint
+        batches = []
+        for bi, (K, seed) in enumerate([(3, 1261), (3, 7), (5, 8), (5, 9), (1, 10)]):
+            U.config.num_unroll_steps = K  # sample_position reads the config, not the argument (utilities.py:104)
+            random.seed(seed)
+            idxes, poss = [], []
+
+            def rec_sample(pop, k):
+                r = orig_sample(pop, k)
+                idxes.extend(r)
+                return r
+
+            def rec_randint(a, b):
+                r = orig_randint(a, b)
+                poss.append(r)
+                return r
+
+            random.sample, random.randint = rec_sample, rec_randint
+            try:
+                img, act, tv, tp = rb.sample_batch(K)
+            finally:
+                random.sample, random.randint = orig_sample, orig_randint
+            pre = "b%d_" % bi
+            out[pre + "K"] = np.int32(K); out[pre + "seed"] = np.int32(seed)
+            out[pre + "game_idx"] = np.array(idxes, np.int32); out[pre + "pos"] = np.array(poss, np.int32)
+            # what update_weights feeds the network: torch.FloatTensor(...) of each (main.py:236)
+            out[pre + "image"] = torch.FloatTensor(img).numpy().astype(np.uint8)
+            out[pre + "actions"] = torch.FloatTensor(act).numpy().astype(np.uint8)
+            out[pre + "target_values"] = torch.FloatTensor(tv).numpy()
+            out[pre + "target_policies"] = torch.FloatTensor(tp).numpy()
+            batches.append((img, act, tv, tp))
+            print("replay batch", bi, "K", K, "idx", idxes, "pos", poss, "tv", tv.T.tolist())
+        out["n_batches"] = np.int32(len(batches))
+        U.config.num_unroll_steps = 3
+        U.config.window_size, U.config.batch_size = 512, 512
+        # ---- update_weights (main.py:230-272) with train_network's optimizer (main.py:206) on batches 0, 1 (K=3), 2 (K=5)
+        torch.manual_seed(1261)
+        net = M.Network()
+        net.train()
+        opt = M.optim.SGD(net.parameters(), lr=0.001, weight_decay=M.config.lr_decay_rate, momentum=M.config.momentum)
+        names = [k for k, _ in net.named_parameters()]
+        out["param_names"] = np.array(names)
+        out["param_shapes"] = np.array([str(tuple(p.shape)) for _, p in net.named_parameters()])
+        gs, ws = [], []
+        orig_step = opt.step
+
+        def rec_step(*a, **k):
+            gs.append(np.array([[float(p.grad.double().sum()), float(p.grad.double().abs().sum())] for p in net.parameters()]))
+            r = orig_step(*a, **k)
+            ws.append(np.array([[float(p.detach().double().sum()), float(p.detach().double().abs().sum())] for p in net.parameters()]))
+            return r
+
+        opt.step = rec_step
+        import io, contextlib
+        logs = []
+        for b in (0, 1, 2, 0):
+            net.steps = 0  # force the loss print (main.py:270-271)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                M.update_weights(opt, net, batches[b])
+            logs.append(buf.getvalue().strip())
+        print("train logs:", logs)
+        out["train_batches"] = np.array([0, 1, 2, 0], np.int32)
+        out["train_grad_sums"] = np.stack(gs); out["train_weight_sums"] = np.stack(ws)
+        out["train_logs"] = np.array(logs)
+        sd = net.state_dict()
+        for k in ("prediction.value_head.3.weight", "prediction.value_head.3.bias", "prediction.policy_head.5.bias",
+                  "dynamics.conv.5.weight"):
+            out["final_" + k] = sd[k].numpy().copy()
+        out["state_dict_keys"] = np.array(list(sd.keys()))
+        out["state_dict_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+    finally:
+        M.Game.legal_actions, M.Game.store_search_statistics = orig_legal, orig_store
+        M.config.num_simulations, M.config.max_moves = 60, 60
+    np.savez_compressed(os.path.join(HERE, "replay.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("env", "all"):
@@ -443,3 +588,5 @@ if __name__ == "__main__":
         gen_features()
     if what in ("game", "all"):
         gen_game()
+    if what in ("replay", "all"):
+        gen_replay()

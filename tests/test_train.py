@@ -1,0 +1,156 @@
+"""Training step (main.py:201-272) on CPU: loss / gradients / SGD update against what the reference's
+own update_weights produced (tests/golden/replay.npz), checkpoint key compatibility, resume, and
+the world_size-2 gloo check of the flat-bucket gradient all-reduce."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(ROOT, "tests", "golden", "replay.npz"))
+TOL = 2e-5  # fp32 sums of up to 147k terms: relative to the abs-sum of the same tensor
+
+
+def batch(b):
+    pre = "b%d_" % b
+    return (G[pre + "image"].astype(np.float32), G[pre + "actions"].astype(np.float32), G[pre + "target_values"],
+            G[pre + "target_policies"])
+
+
+def sums(tensors):
+    return np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in tensors])
+
+
+def close(got, want):
+    return np.all(np.abs(got[:, 0] - want[:, 0]) <= TOL * want[:, 1] + 1e-9) and np.allclose(got[:, 1], want[:, 1], rtol=1e-4, atol=1e-9)
+
+
+def test_state_dict_matches_reference_checkpoint_format():
+    from muzero_amd.network import Network
+    sd = Network().state_dict()
+    assert list(sd.keys()) == G["state_dict_keys"].tolist()
+    assert [str(tuple(v.shape)) for v in sd.values()] == G["state_dict_shapes"].tolist()
+    assert sum(v.numel() for v in sd.values()) == 1836526
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_update_weights_matches_reference(flat, capsys):
+    """4 SGD steps (batches K=3, K=3, K=5, K=3 again): per-parameter gradient sums before every step and
+    weight sums after it equal the reference's; the loss line it prints too"""
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    torch.manual_seed(1261)
+    net = Network()
+    net.train()
+    opt = T.make_optimizer(net)
+    bucket = T.FlatGradBucket(net.parameters()) if flat else None
+    params = list(net.parameters())
+    assert [k for k, _ in net.named_parameters()] == G["param_names"].tolist()
+    for step, b in enumerate(G["train_batches"].tolist()):
+        net.steps = 0
+        seen = {}
+        orig = opt.step
+
+        def rec(*a, **k):
+            seen["g"] = sums([p.grad for p in params])
+            return orig(*a, **k)
+
+        opt.step = rec
+        p_loss, v_loss = T.update_weights(opt, net, batch(b), bucket)
+        opt.step = orig
+        assert close(seen["g"], G["train_grad_sums"][step]), step
+        assert close(sums([p.detach() for p in params]), G["train_weight_sums"][step]), step
+        line = capsys.readouterr().out.strip()
+        assert line == str(G["train_logs"][step]), (line, G["train_logs"][step])
+        assert abs(float(p_loss) - float(line.split()[3])) < 1e-4 and abs(float(v_loss) - float(line.split()[5])) < 1e-4
+    sd = net.state_dict()
+    for k in ("prediction.value_head.3.weight", "prediction.value_head.3.bias", "prediction.policy_head.5.bias", "dynamics.conv.5.weight"):
+        assert np.allclose(sd[k].numpy(), G["final_" + k], rtol=1e-4, atol=1e-7), k
+
+
+def test_checkpoint_roundtrip_and_resume(tmp_path):
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    torch.manual_seed(3)
+    net = Network()
+    opt = T.make_optimizer(net)
+    bucket = T.FlatGradBucket(net.parameters())
+    T.update_weights(opt, net, batch(0), bucket)
+    path = T.save_checkpoint(net, 1000, str(tmp_path), opt)
+    assert path.endswith("1000model.pth")  # main.py:224
+    raw = torch.load(path, map_location="cpu", weights_only=True)  # a plain state_dict, as test.py:247-250 loads it
+    assert list(raw.keys()) == G["state_dict_keys"].tolist()
+    net2 = Network()
+    opt2 = T.make_optimizer(net2)
+    T.load_checkpoint(net2, path, opt2)
+    assert net2.steps == 1
+    b2 = T.FlatGradBucket(net2.parameters())
+    T.update_weights(opt, net, batch(1), bucket)
+    T.update_weights(opt2, net2, batch(1), b2)   # momentum buffers restored -> identical second step
+    for a, b in zip(net.parameters(), net2.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_inference_engine_publish_in_place():
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(1)
+    eng = InferenceEngine(Network(), 4, torch.bfloat16, device="cpu", fused=False)
+    ptrs = [p.data_ptr() for p in eng.net.parameters()]
+    torch.manual_seed(2)
+    new = Network()
+    eng.load_weights(new.state_dict())
+    assert ptrs == [p.data_ptr() for p in eng.net.parameters()]
+    for (k, a), b in zip(eng.net.state_dict().items(), new.state_dict().values()):
+        assert torch.equal(a, b.to(torch.bfloat16)), k
+    with pytest.raises(KeyError):
+        eng.load_weights({"x": torch.zeros(1)})
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    torch.manual_seed(1261 + rank)  # different init on purpose: broadcast_weights must align the replicas
+    net = Network()
+    T.broadcast_weights(net, src=0)
+    opt = T.make_optimizer(net)
+    bucket = T.FlatGradBucket(net.parameters())
+    for b in (0, 1):
+        img, act, tv, tp = batch(b)
+        sl = slice(2 * rank, 2 * rank + 2)  # each rank trains on its half of the 4-sample batch
+        T.update_weights(opt, net, (img[sl], act[:, sl], tv[:, sl], tp[:, sl]), bucket)
+    torch.save(net.state_dict(), os.path.join(out_dir, "rank%d.pth" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce(tmp_path):
+    """2 gloo ranks x half batch == 1 process x whole batch (mean of shard gradients = gradient of the
+    global mean), and both replicas end bit-identical"""
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "rank0.pth"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "rank1.pth"), weights_only=True)
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    torch.manual_seed(1261)
+    net = Network()
+    opt = T.make_optimizer(net)
+    for b in (0, 1):
+        T.update_weights(opt, net, batch(b))
+    for k, v in net.state_dict().items():
+        assert torch.allclose(v, r0[k], rtol=1e-4, atol=1e-6), k
