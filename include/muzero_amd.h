@@ -104,6 +104,14 @@ int mz_make_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_
                   const int32_t *state_index, int32_t state_index_all, void *out, int32_t dtype, int64_t n,
                   void *stream);
 
+/* The arena Controller's observation (test.py:16-29) for n games: planes 6-7 = the current state
+ * (WHITE, BLACK), 4-5 the one before ... over a sliding window of the last 4 observed states that,
+ * unlike make_image, includes the opening position; plane 8 = 1 iff BLACK is to move (= state_index
+ * even for games played from the opening).  Arguments as mz_make_image. */
+int mz_controller_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride,
+                        const int32_t *state_index, int32_t state_index_all, void *out, int32_t dtype, int64_t n,
+                        void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tree search (main.py:99-196, 275-285; reversi.py:234-251 Node; utilities.py:114-129 MinMaxStats)
  * ---------------------------------------------------------------------------------------- */
@@ -218,6 +226,12 @@ int mz_mcts_root_stats(const void *pool, const mz_pool_layout *layout, int32_t *
  * action order.  num_moves: per-game (nullable) else num_moves_all. */
 int mz_select_action(const int32_t *visits, const int32_t *num_moves, int32_t num_moves_all, const double *u,
                      uint8_t *action, int64_t n, void *stream);
+
+/* softmax_sample of the arena (test.py:228-243): temperature 0 = first maximum, 1 = proportional
+ * to N, 0 < t < 1 = proportional to N ** (1/t) (the arena plays t = 0.25, test.py:174); u: (n) f64
+ * uniforms standing for np.random.choice's draw (nullable when temperature == 0). */
+int mz_softmax_sample(const int32_t *visits, double temperature, const double *u, uint8_t *action, int64_t n,
+                      void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Replay buffer + training targets (utilities.py:46-109 ReplayBuffer; reversi.py:314-341 make_target)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mz_env_random_action": [_u64, _u64, _i32, _p, _p, _i64, _p],
     "mz_action_encode": [_p, _p, _p, _i32, _i64, _p],
     "mz_make_image": [_p, _p, _i64, _p, _i32, _p, _i32, _i64, _p],
+    "mz_controller_image": [_p, _p, _i64, _p, _i32, _p, _i32, _i64, _p],
+    "mz_softmax_sample": [_p, C.c_double, _p, _p, _i64, _p],
     "mz_pool_layout_compute": [_i32, _i32, _i32, _LP],
     "mz_pool_init": [_p, _LP, _CP, _p],
     "mz_mcts_root_init": [_p, _LP, _CP, _p, _p, _p, _p, _p, _p, _i32, _p],

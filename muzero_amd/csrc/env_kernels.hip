@@ -288,7 +288,10 @@ __global__ void __launch_bounds__(256) k_action_encode(const uint8_t *action, co
 
 // Game.make_image reversi.py:301-312: planes (3-i)*2, (3-i)*2+1 = WHITE, BLACK discs of state
 // index-i for i < min(index, 4); plane 8 = 1 iff index even.  One thread per 4 cells.
-template <int DT>
+// ARENA: the Controller's observation of test.py:16-29 instead -- a sliding window of the last 4
+// observed states INCLUDING the opening position (state index-i for i <= index), and the last plane
+// set iff the mover is BLACK, which for lock-step games from the opening is again "index even".
+template <int DT, bool ARENA>
 __global__ void __launch_bounds__(256) k_make_image(const uint64_t *hw, const uint64_t *hb, int64_t stride, const int32_t *sidx,
                                                     int sidx_all, typename Elem<DT>::T *out, int64_t n) {
     using T = typename Elem<DT>::T;
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(256) k_make_image(const uint64_t *hw, const ui
         bits = (si & 1) ? 0u : 0xFu;
     } else {
         const int i = 3 - (p >> 1);  // how many states back
-        if (i < si && i < 4) {
+        if ((ARENA ? i <= si : i < si) && i < 4) {
             const uint64_t *h = (p & 1) ? hb : hw;
             bits = (unsigned)(h[(int64_t)(si - i) * stride + g] >> (4 * q)) & 0xFu;
         }
@@ -393,21 +396,38 @@ extern "C" int mz_action_encode(const uint8_t *action, const int8_t *player, voi
     return MZ_OK;
 }
 
-extern "C" int mz_make_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride, const int32_t *state_index,
-                             int32_t state_index_all, void *out, int32_t dtype, int64_t n, void *stream) {
-    MZ_REQUIRE(n >= 0, "mz_make_image: n < 0");
+static int launch_make_image(const char *who, bool arena, const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride,
+                             const int32_t *state_index, int32_t state_index_all, void *out, int32_t dtype, int64_t n, void *stream) {
+    MZ_REQUIRE(n >= 0, "%s: n < 0", who);
     if (n == 0) return MZ_OK;
-    MZ_REQUIRE(hist_white && hist_black && out, "mz_make_image: null pointer");
-    MZ_REQUIRE(hist_stride >= n, "mz_make_image: hist_stride < n");
-    MZ_REQUIRE(state_index || (state_index_all >= 0 && state_index_all <= 60), "mz_make_image: state_index_all out of range");
+    MZ_REQUIRE(hist_white && hist_black && out, "%s: null pointer", who);
+    MZ_REQUIRE(hist_stride >= n, "%s: hist_stride < n", who);
+    MZ_REQUIRE(state_index || (state_index_all >= 0 && state_index_all <= 255), "%s: state_index_all out of range", who);
     const dim3 grid(mz_blocks(n * 144, 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
+#define MZ_IMG(DT, T)                                                                                                              \
+    if (arena) hipLaunchKernelGGL((k_make_image<DT, true>), grid, block, 0, s, hist_white, hist_black, hist_stride, state_index,       \
+                                  (int)state_index_all, (T *)out, n);                                                                  \
+    else hipLaunchKernelGGL((k_make_image<DT, false>), grid, block, 0, s, hist_white, hist_black, hist_stride, state_index,            \
+                            (int)state_index_all, (T *)out, n)
     switch (dtype) {
-        case MZ_F32: hipLaunchKernelGGL(k_make_image<MZ_F32>, grid, block, 0, s, hist_white, hist_black, hist_stride, state_index, (int)state_index_all, (float *)out, n); break;
-        case MZ_BF16: hipLaunchKernelGGL(k_make_image<MZ_BF16>, grid, block, 0, s, hist_white, hist_black, hist_stride, state_index, (int)state_index_all, (uint16_t *)out, n); break;
-        case MZ_F16: hipLaunchKernelGGL(k_make_image<MZ_F16>, grid, block, 0, s, hist_white, hist_black, hist_stride, state_index, (int)state_index_all, (uint16_t *)out, n); break;
-        default: MZ_REQUIRE(false, "mz_make_image: bad dtype %d", dtype);
+        case MZ_F32: MZ_IMG(MZ_F32, float); break;
+        case MZ_BF16: MZ_IMG(MZ_BF16, uint16_t); break;
+        case MZ_F16: MZ_IMG(MZ_F16, uint16_t); break;
+        default: MZ_REQUIRE(false, "%s: bad dtype %d", who, dtype);
     }
+#undef MZ_IMG
     MZ_LAUNCH_CHECK("k_make_image");
     return MZ_OK;
+}
+
+extern "C" int mz_make_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride, const int32_t *state_index,
+                             int32_t state_index_all, void *out, int32_t dtype, int64_t n, void *stream) {
+    return launch_make_image("mz_make_image", false, hist_white, hist_black, hist_stride, state_index, state_index_all, out, dtype, n, stream);
+}
+
+extern "C" int mz_controller_image(const uint64_t *hist_white, const uint64_t *hist_black, int64_t hist_stride, const int32_t *state_index,
+                                   int32_t state_index_all, void *out, int32_t dtype, int64_t n, void *stream) {
+    return launch_make_image("mz_controller_image", true, hist_white, hist_black, hist_stride, state_index, state_index_all, out, dtype, n,
+                             stream);
 }

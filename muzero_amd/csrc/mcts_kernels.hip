@@ -459,6 +459,54 @@ __global__ void __launch_bounds__(256) k_select_action(const int32_t *visits, co
     action[g] = (uint8_t)(out < 0 ? 64 : out);
 }
 
+// softmax_sample of the arena (test.py:228-243; superset of main.py:275-285): temperature 0 = first
+// maximum, 1 = proportional to N, 0 < t < 1 = proportional to N ** (1/t) (Python int ** float =
+// libm pow in double).  When 1/t is a small integer the power is formed by exact multiplications
+// (bit-equal to a correctly rounded pow; exact below 2^53); other temperatures use the device pow.
+__global__ void __launch_bounds__(256) k_softmax_sample(const int32_t *visits, double temperature, const double *u, uint8_t *action,
+                                                        int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int32_t *v = visits + g * MZ_ACTIONS;
+    int best = -1, bestv = -1, last = -1;
+    for (int a = 0; a < MZ_ACTIONS; ++a) {
+        const int x = v[a];
+        if (x < 0) continue;
+        last = a;
+        if (x > bestv) { bestv = x; best = a; }
+    }
+    int out = best;
+    if (temperature != 0.0 && best >= 0) {
+        const double e = 1.0 / temperature;
+        const int ei = (int)e;
+        const bool int_pow = temperature != 1.0 && (double)ei == e && ei >= 1 && ei <= 16;
+        auto weight = [&](int x) -> double {
+            const double d = (double)x;
+            if (temperature == 1.0) return d;
+            if (!int_pow) return pow(d, e);
+            double r = 1.0, b = d;
+            for (int k = ei; k; k >>= 1) { if (k & 1) r *= b; b *= b; }
+            return r;
+        };
+        double wsum = 0.0;
+        for (int a = 0; a < MZ_ACTIONS; ++a)
+            if (v[a] >= 0) wsum += weight(v[a]);
+        double total = 0.0;
+        for (int a = 0; a < MZ_ACTIONS; ++a)
+            if (v[a] >= 0) total += weight(v[a]) / wsum;
+        // np.random.choice(actions, p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+        const double uu = u[g];
+        double c = 0.0;
+        out = last;
+        for (int a = 0; a < MZ_ACTIONS; ++a) {
+            if (v[a] < 0) continue;
+            c += weight(v[a]) / wsum;
+            if (!(c / total <= uu)) { out = a; break; }
+        }
+    }
+    action[g] = (uint8_t)(out < 0 ? 64 : out);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -607,5 +655,15 @@ extern "C" int mz_mcts_node_scores(const void *pool, const mz_pool_layout *L, co
     hipLaunchKernelGGL(k_node_scores, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, node_id, action, score,
                        kind);
     MZ_LAUNCH_CHECK("k_node_scores");
+    return MZ_OK;
+}
+
+extern "C" int mz_softmax_sample(const int32_t *visits, double temperature, const double *u, uint8_t *action, int64_t n, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_softmax_sample: n < 0");
+    MZ_REQUIRE(temperature >= 0.0 && temperature <= 1.0, "mz_softmax_sample: temperature %g outside [0, 1] (test.py:242-243 raises)", temperature);
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(visits && action && (u || temperature == 0.0), "mz_softmax_sample: null pointer");
+    hipLaunchKernelGGL(k_softmax_sample, dim3(mz_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, visits, temperature, u, action, n);
+    MZ_LAUNCH_CHECK("k_softmax_sample");
     return MZ_OK;
 }

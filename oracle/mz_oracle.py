@@ -68,6 +68,11 @@ def lib():
         L.mzo_search_hashnet.argtypes = [p, C.c_int, u64, C.c_int, p, i64, C.c_int, C.c_int, p, p, p]
         L.mzo_play_game_hashnet.restype = C.c_int
         L.mzo_play_game_hashnet.argtypes = [C.c_int, C.c_int] + [p] * 8
+        L.mzo_controller_image.argtypes = [p, p, C.c_int, C.c_int, p]
+        L.mzo_softmax_sample.restype = C.c_int
+        L.mzo_softmax_sample.argtypes = [p, C.c_double, C.c_double]
+        L.mzo_arena_game_hashnet.restype = C.c_int
+        L.mzo_arena_game_hashnet.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, p, C.c_int, p, p, p]
         L.mzo_replay_sample.argtypes = [p] * 5 + [C.c_int] * 3 + [p] * 4
         _lib = L
     return _lib
@@ -258,3 +263,29 @@ def replay_batch(games, picks, K):
     tv = np.stack([o[2] for o in outs], 0).swapaxes(0, 1)
     tp = np.stack([o[3] for o in outs], 0).swapaxes(0, 1)
     return image, np.ascontiguousarray(acts), np.ascontiguousarray(tv), np.ascontiguousarray(tp)
+
+
+# ---------------------------------------------------------------------------------------------
+# arena (test.py)
+# ---------------------------------------------------------------------------------------------
+def controller_image(hist_white, hist_black, state_index, black_to_move):
+    hw = np.ascontiguousarray(hist_white, np.uint64)
+    hb = np.ascontiguousarray(hist_black, np.uint64)
+    out = np.zeros((9, 8, 8), np.float32)
+    lib().mzo_controller_image(ptr(hw), ptr(hb), int(state_index), int(black_to_move), ptr(out))
+    return out
+
+
+def softmax_sample(visits, temperature, u):
+    visits = np.ascontiguousarray(visits, np.int32)
+    return lib().mzo_softmax_sample(ptr(visits), float(temperature), float(u))
+
+
+def arena_game_hashnet(mode_black, mode_white, S, temperature, u, max_steps=60):
+    """-> (steps, actions, white_score, black_score)"""
+    u = np.ascontiguousarray(u, np.float64)
+    actions = np.zeros(max_steps, np.uint8)
+    ws, bs = C.c_int(), C.c_int()
+    n = lib().mzo_arena_game_hashnet(int(mode_black), int(mode_white), int(S), float(temperature), ptr(u), int(max_steps), ptr(actions),
+                                     C.byref(ws), C.byref(bs))
+    return n, actions[:n], ws.value, bs.value

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the committed golden fixtures by IMPORTING the reference (this container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -578,6 +578,80 @@ def gen_replay():
     np.savez_compressed(os.path.join(HERE, "replay.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# arena (test.py): Controller observation, 100-simulation search without noise, t = 0.25 sampling
+# ------------------------------------------------------------------------------------------------
+def gen_arena():
+    import test as RT  # /root/reference/test.py (first on sys.path)
+    assert RT.__file__.startswith("/root/reference")
+    orig_choice = np.random.choice
+    out = {}
+    games = []
+    try:
+        for gi, (mb, mw, seed) in enumerate([("hash", "sat", 21), ("sat", "hash", 22), ("hash", "hash", 23)]):
+            np.random.seed(seed)
+            us = []
+
+            def rec_choice(actions, p=None):
+                st = np.random.get_state()
+                r = orig_choice(actions, p=p)
+                rs = np.random.RandomState()
+                rs.set_state(st)
+                us.append(rs.random_sample())
+                return r
+
+            np.random.choice = rec_choice
+            env = RT.Environment()
+            black_c = RT.Controller(RT.Player.BLACK, HashNetwork(mb))
+            white_c = RT.Controller(RT.Player.WHITE, HashNetwork(mw))
+            acts, imgs = [], []
+            # test.py:51-63 with two harness interventions: legal list sorted by index (H3), and the loop
+            # bounded at 60 steps (the reference's `while not env.done` never ends when step 60 is a pass)
+            while not env.done and env.steps < 60:
+                obs = env.observe()
+                legal = sorted(env.legal_actions, key=lambda a: a.index)
+                mover = env.player
+                a_b = black_c.step(obs, env.player, legal)
+                a_w = white_c.step(obs, env.player, legal)
+                img = np.zeros((9, 8, 8), np.float32)
+                img[:-1] = np.concatenate(black_c.state_history)
+                if mover is RT.Player.BLACK:
+                    img[-1] = 1
+                imgs.append(img.astype(np.uint8))
+                a = a_b if a_b else a_w
+                assert (a_b is None) != (a_w is None)
+                env.step(a)
+                acts.append(a.index)
+            np.random.choice = orig_choice
+            ws, bs = int(np.sum(env.board == 1)), int(np.sum(env.board == -1))
+            games.append(dict(actions=np.array(acts, np.uint8), u=np.array(us, np.float64), images=np.stack(imgs),
+                              white_score=ws, black_score=bs, done=int(env.done)))
+            print("arena game", gi, mb, "vs", mw, "steps", len(acts), "done", env.done, "white", ws, "black", bs)
+            out["mode_black_%d" % gi] = np.int32(R.MODES[mb]); out["mode_white_%d" % gi] = np.int32(R.MODES[mw])
+            for k, v in games[-1].items():
+                out["%s_%d" % (k, gi)] = np.asarray(v)
+        out["n_games"] = np.int32(len(games))
+        # softmax_sample (test.py:228-243) on its own: temperatures 0 / 0.25 / 0.5 / 1 over random visit vectors
+        rng = np.random.RandomState(5)
+        V, T, U, A = [], [], [], []
+        for i in range(200):
+            k = rng.randint(1, 12)
+            acts = sorted(rng.choice(65, k, replace=False).tolist())
+            vis = rng.randint(0, 101, k)
+            vis[rng.randint(k)] += 1
+            t = [0, 0.25, 0.5, 1][i % 4]
+            np.random.seed(1000 + i)
+            st = np.random.get_state()
+            a = RT.softmax_sample(list(zip(vis.tolist(), acts)), t)
+            rs = np.random.RandomState(); rs.set_state(st)
+            v = np.full(65, -1, np.int32); v[acts] = vis
+            V.append(v); T.append(t); U.append(rs.random_sample()); A.append(int(a))
+        out.update(ss_visits=np.stack(V), ss_t=np.array(T), ss_u=np.array(U), ss_action=np.array(A, np.int32))
+    finally:
+        np.random.choice = orig_choice
+    np.savez_compressed(os.path.join(HERE, "arena.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("env", "all"):
@@ -590,3 +664,5 @@ if __name__ == "__main__":
         gen_game()
     if what in ("replay", "all"):
         gen_replay()
+    if what in ("arena", "all"):
+        gen_arena()
