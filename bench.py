@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--selfplay-sims", type=int, default=50)
     ap.add_argument("--skip-extras", action="store_true", help="only the timed MCTS leg")
     ap.add_argument("--cpu-trees", type=int, default=4096)
+    ap.add_argument("--train-batch", type=int, default=512, help="config.py:34 batch_size for the training leg (0 = skip)")
+    ap.add_argument("--train-unroll", type=int, default=5, help="K (BASELINE configs[4]: 5; config.py:36: 3)")
     return ap.parse_args()
 
 
@@ -139,6 +141,39 @@ def bench_env(args, device):
                          "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP,
                          "us_per_launch": ms_step * 1e3},
     }
+
+
+def bench_train(args, device, rec):
+    """replay window -> sample_batch (HIP) -> update_weights (PyTorch fp32, flat gradient bucket)"""
+    import random
+    from muzero_amd import config, train as T
+    from muzero_amd.network import Network
+    from muzero_amd.replay import ReplayBuffer
+    B, K = args.train_batch, args.train_unroll
+    config.num_unroll_steps = K
+    rb = ReplayBuffer(device, window_size=max(rec.n, B), batch_size=B)
+    while rb.buffer_size < B:
+        rb.save_games(rec)
+    random.seed(1261)
+    torch.manual_seed(1261)
+    net = Network().to(device)
+    net.train()
+    opt = T.make_optimizer(net)
+    bucket = T.FlatGradBucket(net.parameters())
+    net.steps = 1  # no loss print inside the timed loop
+    for _ in range(3):
+        T.update_weights(opt, net, rb.sample_batch(K), bucket)
+    torch.cuda.synchronize()
+    ms_sample = event_time_ms(lambda: rb.sample_batch(K), 20)
+    t0 = time.perf_counter()
+    iters = 10
+    for _ in range(iters):
+        p_loss, v_loss = T.update_weights(opt, net, rb.sample_batch(K), bucket)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    config.num_unroll_steps = 3
+    return {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
+            "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss)}
 
 
 def bench_cpu_baseline(args):
@@ -303,6 +338,8 @@ def main():
             dts = time.perf_counter() - t1
             out["selfplay"] = {"games": g, "simulations": args.selfplay_sims, "moves": rec.length, "seconds": dts,
                                "games_per_sec": g / dts, "simulations_per_sec": g * rec.length * args.selfplay_sims / dts}
+            if args.train_batch > 0:
+                out["train"] = bench_train(args, device, rec)
         out["cpu_baseline"] = bench_cpu_baseline(args)
     if dist is not None:
         dist.barrier()

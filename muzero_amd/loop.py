@@ -1,0 +1,83 @@
+"""muzero() -- the reference's top-level loop (main.py:25-65) as one process per GPU.
+
+Reference: Ray starts cpu_count()-2 self-play actors that push finished games into a ReplayBuffer
+actor while the trainer samples from it (main.py:26-39, 55-63, 201-227).  Here every rank of a
+torch.distributed job (RCCL on the GPUs; none needed for one GPU) alternates, per generation:
+
+  1. self-play: `games_per_rank` lock-step games on the rank's own game-id block (no collective);
+  2. trajectory gather: one all_gather of the fixed-size game records (shard.gather_game_records) so
+     every rank's replay window holds the same games in the same (game-id) order;
+  3. training: `train_steps` x (sample_batch on the rank's shard of the global batch ->
+     update_weights with ONE flat-bucket gradient all-reduce);
+  4. publish: the new weights are copied in place into the rank's InferenceEngine (the parameter
+     storage a captured hipGraph replays against) -- SharedStorage.save_network / run_selfplay's
+     load_state_dict (main.py:60-61, 216-221) without Ray.
+
+All ranks draw the same (game, position) pairs from `random` (seeded identically, main.py:19) and
+take disjoint slices of them, so an N-GPU run trains on exactly the batch a 1-GPU run would.
+"""
+import random
+
+import torch
+import torch.distributed as dist
+
+from . import config
+from .network import InferenceEngine, Network
+from .replay import ReplayBuffer
+from .selfplay import SelfPlayEngine
+from .shard import gather_game_records
+from . import train as T
+
+
+class MuZeroLoop:
+    def __init__(self, games_per_rank, device="cuda", infer_dtype=torch.bfloat16, num_simulations=None, window_size=None,
+                 batch_size=None, seed=1261, use_graph=True, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if T._dist_on(group) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.device = torch.device(device)
+        torch.manual_seed(seed)          # main.py:18: identical initial weights on every rank
+        random.seed(seed)                # main.py:19: identical replay draws on every rank
+        self.network = Network().to(self.device)
+        self.network.train()
+        self.optimizer = T.make_optimizer(self.network)
+        self.bucket = T.FlatGradBucket(self.network.parameters())
+        self.storage = T.SharedStorage(self.network.state_dict())
+        serve = Network()
+        serve.load_state_dict(self.network.state_dict())
+        self.infer = InferenceEngine(serve, games_per_rank, infer_dtype, device=self.device)
+        self.selfplay = SelfPlayEngine(games_per_rank, self.infer, num_simulations=num_simulations, device=self.device,
+                                       use_graph=use_graph, seed=seed + 7919 * self.rank)
+        self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
+        if self.batch_size % self.world:
+            raise ValueError("global batch %d is not divisible by %d ranks" % (self.batch_size, self.world))
+        self.replay = ReplayBuffer(self.device, window_size=window_size, batch_size=self.batch_size)
+        self.losses = []
+
+    def generation(self, train_steps):
+        """one self-play round + `train_steps` updates; returns the losses of this generation"""
+        rec = self.selfplay.play_games()
+        full = gather_game_records(rec, self.group) if self.world > 1 else rec
+        self.replay.save_games(full, lengths=rec.length)
+        out = []
+        if self.replay.ready():
+            K = config.num_unroll_steps
+            shard = self.batch_size // self.world
+            for _ in range(train_steps):
+                idx = random.sample(range(self.replay.buffer_size), self.batch_size)   # utilities.py:76
+                pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
+                sl = slice(self.rank * shard, (self.rank + 1) * shard)
+                batch = self.replay.sample_batch(K, idx[sl], pos[sl])
+                out.append(T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group))
+            self.storage.save_network(self.network.state_dict())
+            self.infer.load_weights(self.storage.get_network())
+        self.losses.extend(out)
+        return out
+
+
+def muzero(generations=1, games_per_rank=None, train_steps=None, **kw):
+    """main.py:25-39 for this rank; returns the MuZeroLoop (weights, replay window, losses)."""
+    loop = MuZeroLoop(games_per_rank or config.batch_size, **kw)
+    for _ in range(generations):
+        loop.generation(train_steps if train_steps is not None else config.training_steps)
+    return loop
