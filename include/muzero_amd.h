@@ -283,6 +283,27 @@ int mz_replay_sample_batch(const mz_replay *rb, const int32_t *slot, const int32
 int mz_bias_act_nhwc(void *y, const void *bias, const void *residual, int64_t n_elems, int32_t channels,
                      int32_t dtype, int32_t relu, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Convolution tower (network.py:49-77 Representation, :113-135 Dynamics) as one LDS-resident MFMA
+ * kernel: conv3x3 cin->128 + ReLU, three ResidualBlocks (network.py:35-47), conv3x3 128->8 + ReLU.
+ * bf16 operands, fp32 accumulation, one bf16 rounding per layer output.  Activations never leave
+ * LDS between layers (tower_kernels.hip); the prediction heads stay in PyTorch.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muzero_amd.network.pack_tower) */
+    const void *w_first;   /* bf16 [9 taps][128 co][16 ci]      conv1 / dynamics conv.0, ci zero-padded; tap = ky*3+kx */
+    const float *b_first;  /* f32 [128] or NULL (Dynamics' first conv has no bias, network.py:119) */
+    const void *w_mid;     /* bf16 [6 layers][18 stages][128 co][8 slots][8]: stage = tap*2 + (ci >= 64),
+                              16-byte chunk c of the 64 input channels stored in slot c ^ ((co >> 1) & 7) */
+    const float *b_mid;    /* f32 [6][128] */
+    const void *w_last;    /* bf16 [18 stages][32 co (rows 8..31 zero)][8 slots][8], same chunk swizzle */
+    const float *b_last;   /* f32 [8] or NULL (network.py:127) */
+    int32_t cin;           /* input planes: 9 (Representation) or 10 (Dynamics: hidden ++ action planes) */
+} mz_tower_weights;
+
+/* x: (n,cin,8,8) bf16 NCHW (e.g. the net_in rows mz_mcts_select writes); hidden: (n,8,8,8) NCHW of
+ * hidden_dtype (MZ_BF16 or MZ_F32).  One workgroup per 4 boards. */
+int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,12 @@ class Replay(C.Structure):
                 ("window", C.c_int32), ("max_moves", C.c_int32)]
 
 
+class TowerWeights(C.Structure):
+    """mz_tower_weights -- device pointers to the prepacked tower weights"""
+    _fields_ = [("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
+                ("w_last", C.c_void_p), ("b_last", C.c_void_p), ("cin", C.c_int32)]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "muzero_amd: %s is missing. Build it with `make -C muzero_amd/csrc` (or "
@@ -72,6 +78,7 @@ SIGNATURES = {
     "mz_mcts_root_stats": [_p, _LP, _p, _p, _p, _p, _i32, _p],
     "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
     "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    "mz_tower_forward": [C.POINTER(TowerWeights), _p, _p, _i32, _i64, _p],
     "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }

@@ -1,0 +1,347 @@
+// tower_kernels.hip -- the MuZero convolution tower as ONE LDS-resident MFMA kernel for gfx950.
+//
+// Replaces, for bf16 serving, the per-layer PyTorch/MIOpen calls of network.py:49-77
+// (Representation) and network.py:113-135 (Dynamics): 3x3 conv Cin->128 + ReLU, three residual
+// blocks relu(x + conv(relu(conv(x)))) (network.py:35-47), 3x3 conv 128->8 + ReLU.  The prediction
+// heads (network.py:79-111) stay in PyTorch.
+//
+// Why one kernel.  An 8x8 board with 128 channels is 16 KB in bf16, so FOUR boards (256 positions,
+// the GEMM M dimension) and both activation tensors a residual block needs fit in the 160 KB LDS of
+// one CU.  A workgroup therefore carries its four boards through all eight layers without ever
+// writing an activation to HBM: per tile it reads 5 KB of input planes, writes 4 KB of hidden
+// state, and streams the layer weights (295 KB per 128->128 layer, L2-resident: every workgroup
+// reads the same 1.9 MB) through a double-buffered 2 x 16 KB LDS stage.  HBM traffic drops from
+// ~200 MB per layer to ~10 MB per tower; what is left is MFMA work.
+//
+// Mapping (one workgroup = 512 threads = 8 waves, 2 per SIMD; static LDS = 163,840 B):
+//   GEMM per layer: D[co][pos] = sum_{tap,ci} W[tap][co][ci] * X[pos + shift(tap)][ci]
+//   MFMA v_mfma_f32_32x32x16_bf16 with A = weights (rows = co), B = activations (cols = pos), so a
+//   lane ends up holding ONE position and 4-element runs of consecutive channels: the epilogue
+//   (bias, residual, ReLU, bf16 rounding) writes 8-byte pieces straight back into the [pos][ch] LDS
+//   image the next layer reads -- no transpose, no shuffle.
+//   wave w: co half (w & 1) x board (w >> 1)  ->  2 x 2 accumulator tiles of 32 x 32 per wave.
+//   K loop: 9 taps x 2 half-channel chunks = 18 stages of [128 co][64 ci]; one barrier per stage;
+//   stage s+1 is fetched into registers while stage s computes (register-staged, written to the
+//   other LDS buffer before the barrier).
+//   The 3x3 halo is handled by masking: a lane whose shifted position leaves the board gets a zero
+//   fragment (v_cndmask), so the activation image needs no padding ring.
+// LDS images are XOR-swizzled in 16-byte chunks so every ds_read_b128 lane group hits 16 distinct
+// 4-bank slots: activations  slot = chunk ^ ((y & 1) << 3 | x),  weights  slot = chunk ^ ((co >> 1) & 7).
+// Weights arrive PREPACKED in exactly these images (muzero_amd/network.py: pack_tower), so staging
+// is a linear copy.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TILE_BOARDS = 4;
+constexpr int TILE_POS = 256;
+constexpr int ACT_BYTES = TILE_POS * 128 * 2;  // 65,536: one [256 pos][128 ch] bf16 image
+constexpr int WSTAGE_BYTES = 128 * 64 * 2;     // 16,384: one [128 co][64 ci] weight stage
+constexpr int OFF_X = 0, OFF_T = ACT_BYTES, OFF_W = 2 * ACT_BYTES;
+constexpr int LDS_BYTES = 2 * ACT_BYTES + 2 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
+constexpr int N_STAGES = 18;
+constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
+constexpr int LAST_W_BYTES = N_STAGES * 32 * 64 * 2;  // 73,728
+
+struct Tower {
+    const uint4 *w_first;  // [9][128 co][16 ci] bf16
+    const float *b_first;  // [128] or null
+    const uint4 *w_mid;    // [6][18][128 co][8 slots][8] bf16, slot = chunk ^ ((co >> 1) & 7)
+    const float *b_mid;    // [6][128]
+    const uint4 *w_last;   // [18][32 co (8 real)][8 slots][8] bf16, same swizzle
+    const float *b_last;   // [8] or null
+    int cin;               // real input planes (9 or 10)
+};
+
+__device__ __forceinline__ int act_key(int q) { return (((q >> 3) & 1) << 3) | (q & 7); }
+
+__device__ __forceinline__ uint32_t bf16_rne(float f) {  // finite inputs (post-ReLU)
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_up(uint32_t v) { return __uint_as_float(v << 16); }
+
+// validity of (tap, position tile j) for this lane: bit tap*2+j.  Position tile j of a board covers
+// rows 4j..4j+3; the lane's cell is row 4j + (r >> 3), column r & 7.
+__device__ __forceinline__ uint32_t halo_mask(int r) {
+    uint32_t m = 0;
+    const int x = r & 7;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int xx = x + kx - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int yy = 4 * j + (r >> 3) + ky - 1;
+            if (xx >= 0 && xx <= 7 && yy >= 0 && yy <= 7) m |= 1u << (tap * 2 + j);
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+__device__ __forceinline__ bf16x8 zero_frag() {
+    bf16x8 z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.0f;
+    return z;
+}
+
+// ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
+template <bool RES>
+__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+                                          int tid, uint32_t vm) {
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
+
+    // stage 0 -> buffer 0
+    uint4 st0 = wp[tid], st1 = wp[tid + 512];
+    *reinterpret_cast<uint4 *>(lds + OFF_W + tid * 16) = st0;
+    *reinterpret_cast<uint4 *>(lds + OFF_W + (tid + 512) * 16) = st1;
+    __syncthreads();
+
+    int wrow[2], wkey[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int co = cobase + 32 * i + r;
+        wrow[i] = co * 128;
+        wkey[i] = (co >> 1) & 7;
+    }
+    const char *src = lds + src_off;
+
+#pragma unroll
+    for (int s = 0; s < N_STAGES; ++s) {
+        const int tap = s >> 1, kc = s & 1;
+        const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+        if (s + 1 < N_STAGES) {
+            st0 = wp[(s + 1) * 1024 + tid];
+            st1 = wp[(s + 1) * 1024 + tid + 512];
+        }
+        const char *wb = lds + OFF_W + (s & 1) * WSTAGE_BYTES;
+        int arow[2], akey[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q2 = (posbase + 32 * j + r + dq) & 255;
+            arow[j] = q2 * 256;
+            akey[j] = act_key(q2);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = lds_frag(wb + wrow[i] + (((kk * 2 + h) ^ wkey[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b[j] = lds_frag(src + arow[j] + (((kc * 8 + kk * 2 + h) ^ akey[j]) << 4));
+                if (tap != 4 && !((vm >> (tap * 2 + j)) & 1u)) b[j] = zero_frag();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < N_STAGES) {
+            char *nb = lds + OFF_W + ((s + 1) & 1) * WSTAGE_BYTES;
+            *reinterpret_cast<uint4 *>(nb + tid * 16) = st0;
+            *reinterpret_cast<uint4 *>(nb + (tid + 512) * 16) = st1;
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane = position, registers 4g..4g+3 = channels co0..co0+3
+    char *dst = lds + dst_off;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = cobase + 32 * i + 8 * g + 4 * h;
+            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + co0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = posbase + 32 * j + r;
+                char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] + bv[k];
+                if (RES) {
+                    const uint2 x = *reinterpret_cast<const uint2 *>(p);
+                    v[0] += bf16_up(x.x & 0xFFFFu);
+                    v[1] += bf16_up(x.x >> 16);
+                    v[2] += bf16_up(x.y & 0xFFFFu);
+                    v[3] += bf16_up(x.y >> 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.0f);
+                uint2 o;
+                o.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+                o.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(p) = o;
+            }
+        }
+    __syncthreads();
+}
+
+// ---- first layer: input planes (global, NCHW) -> X.  Uses the T region as scratch: [256 pos][16 ch]
+// input image at OFF_T, all 9 tap weight slabs [9][128 co][16 ci] behind it. ---------------------------
+__device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const uint16_t *__restrict__ x, int64_t board0, int64_t n_boards, int tid,
+                                            uint32_t vm) {
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
+    char *in = lds + OFF_T;
+    char *wf = lds + OFF_T + TILE_POS * 32;
+    {   // input: thread -> position tid & 255, channels 8*(tid >> 8) .. +7
+        const int q = tid & 255, part = tid >> 8;
+        const int64_t b = board0 + (q >> 6);
+        uint32_t pk[4] = {0, 0, 0, 0};
+        if (b < n_boards) {
+            const uint16_t *px = x + b * tw.cin * 64 + (q & 63);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int c = part * 8 + k;
+                const uint32_t v = c < tw.cin ? (uint32_t)px[c * 64] : 0u;
+                pk[k >> 1] |= v << ((k & 1) * 16);
+            }
+        }
+        *reinterpret_cast<uint4 *>(in + q * 32 + part * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        for (int i = tid; i < FIRST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wf + i * 16) = tw.w_first[i];
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = lds_frag(wf + (tap * 128 + cobase + 32 * i + r) * 32 + h * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q2 = (posbase + 32 * j + r + dq) & 255;
+            b[j] = lds_frag(in + q2 * 32 + h * 16);
+            if (tap != 4 && !((vm >> (tap * 2 + j)) & 1u)) b[j] = zero_frag();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    char *dst = lds + OFF_X;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = cobase + 32 * i + 8 * g + 4 * h;
+            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (tw.b_first) bv = *reinterpret_cast<const f32x4 *>(tw.b_first + co0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = posbase + 32 * j + r;
+                char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][j][4 * g + k] + bv[k], 0.0f);
+                uint2 o;
+                o.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
+                o.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(p) = o;
+            }
+        }
+    __syncthreads();
+}
+
+// ---- last layer: X -> hidden (global, NCHW, 8 planes).  All 18 weight stages [32 co][64 ci] sit in
+// LDS at once (T + stage buffers = 96 KB free); wave w owns positions 32w .. 32w+31. -------------------
+template <int OUT_DT>
+__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid,
+                                           uint32_t vm) {
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    char *wl = lds + OFF_T;
+    for (int i = tid; i < LAST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wl + i * 16) = tw.w_last[i];
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+    const char *src = lds + OFF_X;
+    const int jt = w & 1, wkey = (r >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < N_STAGES; ++s) {
+        const int tap = s >> 1, kc = s & 1;
+        const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+        const int q2 = (32 * w + r + dq) & 255;
+        const int arow = q2 * 256, akey = act_key(q2);
+        const bool ok = tap == 4 || ((vm >> (tap * 2 + jt)) & 1u);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 a = lds_frag(wl + s * 4096 + r * 128 + (((kk * 2 + h) ^ wkey) << 4));
+            bf16x8 b = lds_frag(src + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4));
+            if (!ok) b = zero_frag();
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+    // rows co = (reg & 3) + 8 (reg >> 2) + 4 h: the 8 real planes are registers 0..3 of both lane halves
+    const int64_t b = board0 + (w >> 1);
+    if (b < n_boards) {
+        const int cell = 32 * (w & 1) + r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = 4 * h + k;
+            const float v = fmaxf(acc[k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
+            const int64_t o = b * 512 + co * 64 + cell;
+            if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = v;
+            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)bf16_rne(v);
+        }
+    }
+}
+
+template <int OUT_DT>
+__global__ void __launch_bounds__(512) k_tower(Tower tw, const uint16_t *__restrict__ x, void *__restrict__ hidden, int64_t n_boards) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x;
+    const uint32_t vm = halo_mask(tid & 31);
+    const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
+    layer_first(lds, tw, x, board0, n_boards, tid, vm);
+#pragma unroll 1
+    for (int blk = 0; blk < 3; ++blk) {
+        const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 1024;
+        const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 1024;
+        layer_mid<false>(lds, OFF_X, OFF_T, w0, tw.b_mid + (2 * blk) * 128, tid, vm);      // t = relu(conv(x))
+        layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm);   // x = relu(x + conv(t))
+    }
+    layer_last<OUT_DT>(lds, tw, hidden, board0, n_boards, tid, vm);
+}
+
+}  // namespace
+
+extern "C" int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream) {
+    MZ_REQUIRE(w, "mz_tower_forward: null weights");
+    MZ_REQUIRE(n >= 0, "mz_tower_forward: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(w->w_first && w->w_mid && w->b_mid && w->w_last && x && hidden, "mz_tower_forward: null pointer");
+    MZ_REQUIRE(w->cin >= 1 && w->cin <= 16, "mz_tower_forward: cin %d outside [1, 16]", w->cin);
+    MZ_REQUIRE(hidden_dtype == MZ_BF16 || hidden_dtype == MZ_F32, "mz_tower_forward: hidden dtype must be bf16 or f32");
+    MZ_REQUIRE((((uintptr_t)w->w_first | (uintptr_t)w->w_mid | (uintptr_t)w->w_last | (uintptr_t)w->b_mid | (uintptr_t)w->b_first) & 15) == 0,
+               "mz_tower_forward: weight pointers must be 16-byte aligned");
+    Tower tw{(const uint4 *)w->w_first, w->b_first, (const uint4 *)w->w_mid, w->b_mid, (const uint4 *)w->w_last, w->b_last, w->cin};
+    const dim3 grid((unsigned)((n + TILE_BOARDS - 1) / TILE_BOARDS)), block(512);
+    if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, tw, (const uint16_t *)x, hidden, n);
+    else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, tw, (const uint16_t *)x, hidden, n);
+    MZ_LAUNCH_CHECK("k_tower");
+    return MZ_OK;
+}

@@ -123,6 +123,49 @@ class Network(nn.Module):
         return self.steps
 
 
+def _swizzle_rows(w):
+    """(rows, 64 ci) -> (rows, 8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ ((co >> 1) & 7) -- the LDS
+    image tower_kernels.hip reads conflict-free (XOR is an involution, so slot s holds chunk s ^ key)"""
+    rows = w.shape[0]
+    ch = w.reshape(rows, 8, 8)
+    key = (torch.arange(rows, device=w.device) >> 1) & 7
+    idx = torch.arange(8, device=w.device).unsqueeze(0) ^ key.unsqueeze(1)      # (rows, 8): chunk held by each slot
+    return torch.gather(ch, 1, idx.unsqueeze(-1).expand(rows, 8, 8))
+
+
+def _pack_stages(w, rows):
+    """conv weight (co, 128, 3, 3) -> (18 stages, rows, 8, 8): stage = (ky*3+kx)*2 + (ci >= 64), co zero-padded to rows"""
+    co = w.shape[0]
+    out = []
+    for tap in range(9):
+        for kc in range(2):
+            blk = torch.zeros((rows, 64), dtype=w.dtype, device=w.device)
+            blk[:co] = w[:, kc * 64:(kc + 1) * 64, tap // 3, tap % 3]
+            out.append(_swizzle_rows(blk))
+    return torch.stack(out)
+
+
+def pack_tower(first, blocks, last, device, cin):
+    """Prepack one tower (first conv, three ResidualBlocks, last conv -- network.py:54-68 / :118-128) into the
+    bf16 LDS images mz_tower_forward streams (include/muzero_amd.h mz_tower_weights).  Returns a dict of device
+    tensors (kept alive by the caller) holding the layout documented there."""
+    bf = torch.bfloat16
+    f32 = lambda b, n: (torch.zeros(n) if b is None else b.detach().float()).to(device).contiguous()  # noqa: E731
+    wf = torch.zeros((9, 128, 16), dtype=torch.float32)
+    w1 = first.weight.detach().float().cpu()
+    for tap in range(9):
+        wf[tap, :, :cin] = w1[:, :, tap // 3, tap % 3]
+    mids, bmid = [], []
+    for blk in blocks:
+        for conv in (blk.block[0], blk.block[2]):
+            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128))
+            bmid.append(conv.bias.detach().float().cpu())
+    return dict(w_first=wf.to(bf).to(device).contiguous(), b_first=None if first.bias is None else f32(first.bias, 128),
+                w_mid=torch.stack(mids).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),
+                w_last=_pack_stages(last.weight.detach().float().cpu(), 32).to(bf).to(device).contiguous(),
+                b_last=None if last.bias is None else f32(last.bias, 8), cin=int(cin))
+
+
 class InferenceEngine:
     """Serves a Network to the batched search: fixed batch size, fixed dtype / memory format.
 
@@ -134,7 +177,7 @@ class InferenceEngine:
     (``mz_bias_act_nhwc``): same arithmetic in fp32, one rounding instead of up to three.
     """
 
-    def __init__(self, network, batch, dtype=torch.float32, channels_last=True, device="cuda", fused=True):
+    def __init__(self, network, batch, dtype=torch.float32, channels_last=True, device="cuda", fused=True, tower="auto"):
         self.device = torch.device(device)
         self.batch = int(batch)
         self.dtype = dtype
@@ -146,11 +189,53 @@ class InferenceEngine:
             self.net = self.net.to(memory_format=torch.channels_last)
         for p in self.net.parameters():
             p.requires_grad_(False)
-        self.fused = bool(fused and channels_last)
-        if self.fused:
+        # tower = "hip": both convolution towers run as the LDS-resident MFMA kernel (mz_tower_forward, bf16 only);
+        # "miopen": PyTorch/MIOpen convolutions (+ the fused epilogue when fused=True).  "auto" = hip for bf16 on a GPU.
+        if tower == "auto":
+            tower = "hip" if (dtype == torch.bfloat16 and self.device.type == "cuda") else "miopen"
+        if tower not in ("hip", "miopen"):
+            raise ValueError("tower must be 'auto', 'hip' or 'miopen'")
+        if tower == "hip" and dtype != torch.bfloat16:
+            raise ValueError("the HIP tower serves bf16 only")
+        self.tower = tower
+        self.fused = bool(fused and channels_last and self.device.type == "cuda")
+        if self.fused or tower == "hip":
             from . import _lib
             self._L = _lib
             self._dt = {torch.float32: _lib.MZ_F32, torch.bfloat16: _lib.MZ_BF16, torch.float16: _lib.MZ_F16}[dtype]
+        if tower == "hip":
+            self._packs = {}
+            self._repack()
+
+    # ---- HIP tower ---------------------------------------------------------------------------------
+    def _tower_parts(self):
+        r, d = self.net.representation, self.net.dynamics.conv
+        return {"repr": (r.conv1[0], list(r.conv2), r.conv3[0], config.state_shape[0]),
+                "dyn": (d[0], [d[2], d[3], d[4]], d[5], HIDDEN_PLANES + 2)}
+
+    def _repack(self):
+        """(re)build the prepacked weight images IN PLACE (a captured hipGraph holds their addresses)"""
+        L = self._L
+        for name, (first, blocks, last, cin) in self._tower_parts().items():
+            new = pack_tower(first, blocks, last, self.device, cin)
+            if name not in self._packs:
+                ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+                new["struct"] = L.TowerWeights(ptr(new["w_first"]), ptr(new["b_first"]), ptr(new["w_mid"]), ptr(new["b_mid"]),
+                                               ptr(new["w_last"]), ptr(new["b_last"]), new["cin"])
+                self._packs[name] = new
+            else:
+                for k, t in new.items():
+                    if torch.is_tensor(t):
+                        self._packs[name][k].copy_(t)
+
+    def _tower_hip(self, name, x):
+        L = self._L
+        pk = self._packs[name]
+        if x.dtype != torch.bfloat16 or not x.is_contiguous() or tuple(x.shape[1:]) != (pk["cin"], 8, 8):
+            raise L.MzError("HIP tower input must be a contiguous bf16 (n,%d,8,8) tensor" % pk["cin"])
+        hidden = torch.empty((x.shape[0], HIDDEN_PLANES, 8, 8), dtype=torch.bfloat16, device=x.device)
+        L.call("mz_tower_forward", L.C.byref(pk["struct"]), L.dptr(x), L.dptr(hidden), L.MZ_BF16, x.shape[0], L.current_stream())
+        return hidden
 
     @torch.no_grad()
     def load_weights(self, state_dict):
@@ -163,6 +248,8 @@ class InferenceEngine:
             raise KeyError("state_dict mismatch: %s" % sorted(missing))
         for k, t in own.items():
             t.copy_(state_dict[k])
+        if self.tower == "hip":
+            self._repack()
 
     # ---- fused tower: conv (MIOpen, no bias) + one epilogue pass ---------------------------------
     def _epi(self, y, bias, residual=None):
@@ -186,12 +273,18 @@ class InferenceEngine:
 
     def _hidden_initial(self, image):
         r = self.net.representation
+        if self.tower == "hip":
+            return self._tower_hip("repr", image.contiguous())
+        image = image.contiguous(memory_format=self.mf)
         if not self.fused:
             return r(image)
         return self._tower(image, r.conv1[0], list(r.conv2), r.conv3[0])
 
     def _hidden_recurrent(self, x10):
         d = self.net.dynamics.conv
+        if self.tower == "hip":
+            return self._tower_hip("dyn", x10.contiguous())
+        x10 = x10.contiguous(memory_format=self.mf)
         if not self.fused:
             return d(x10)
         return self._tower(x10, d[0], [d[2], d[3], d[4]], d[5])
@@ -203,8 +296,8 @@ class InferenceEngine:
 
     @torch.no_grad()
     def initial(self, image):
-        return self._finish(self._hidden_initial(image.to(self.dtype).contiguous(memory_format=self.mf)))
+        return self._finish(self._hidden_initial(image.to(self.dtype)))
 
     @torch.no_grad()
     def recurrent(self, x10):
-        return self._finish(self._hidden_recurrent(x10.contiguous(memory_format=self.mf)))
+        return self._finish(self._hidden_recurrent(x10))

@@ -35,8 +35,8 @@ def test_fused_engine_matches_module_forward(dtype, tol):
     torch.manual_seed(1261)
     net = Network()
     B = 192
-    fused = InferenceEngine(net, B, dtype, fused=True)
-    plain = InferenceEngine(net, B, dtype, fused=False)
+    fused = InferenceEngine(net, B, dtype, fused=True, tower="miopen")
+    plain = InferenceEngine(net, B, dtype, fused=False, tower="miopen")
     img = (torch.rand(B, 9, 8, 8, device="cuda") < 0.3).float()
     x10 = torch.rand(B, 10, 8, 8, device="cuda").to(dtype)
     for a, b in ((fused.initial(img), plain.initial(img)), (fused.recurrent(x10), plain.recurrent(x10))):
@@ -49,3 +49,70 @@ def test_fused_engine_matches_module_forward(dtype, tol):
             v, p, h = net.recurrent_inference(x10[:, :8], x10[:, 8:])
         a = fused.recurrent(x10)
         assert (a[0] - v.reshape(-1)).abs().max().item() < 1e-5 and (a[1] - p).abs().max().item() < 1e-5
+
+
+def _ref_tower(x, first, blocks, last):
+    """fp32 torch reference of the tower with the kernel's rounding points: bf16 weights and inputs,
+    fp32 accumulation, one bf16 rounding of every layer output (bias / residual / ReLU applied in fp32)"""
+    import torch.nn.functional as F
+    q = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    conv = lambda y, c: F.conv2d(y, q(c.weight.float()), None if c.bias is None else c.bias.float(), 1, 1)  # noqa: E731
+    y = q(torch.relu(conv(x.float(), first)))
+    for blk in blocks:
+        t = q(torch.relu(conv(y, blk.block[0])))
+        y = q(torch.relu(y + conv(t, blk.block[2])))
+    return q(torch.relu(conv(y, last)))
+
+
+@pytest.mark.parametrize("n", [4096, 203, 1])
+def test_hip_tower_vs_torch_fp32_reference(n):
+    """mz_tower_forward (both towers) through the C ABI against the fp32 reference; ragged n covers partial tiles"""
+    from muzero_amd.network import InferenceEngine, Network
+    torch.backends.cudnn.allow_tf32 = False
+    torch.manual_seed(1261)
+    net = Network()
+    with torch.no_grad():   # default init gives tiny biases: make them matter, asymmetric
+        for p in net.parameters():
+            if p.ndim == 1:
+                p.uniform_(-0.3, 0.3)
+    eng = InferenceEngine(net, n, torch.bfloat16, tower="hip")
+    ref = Network().cuda()
+    ref.load_state_dict(net.state_dict())
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    img = (torch.rand(n, 9, 8, 8, device="cuda", generator=gen) < 0.3).to(torch.bfloat16)
+    x10 = torch.rand(n, 10, 8, 8, device="cuda", generator=gen).to(torch.bfloat16)
+    r, d = ref.representation, ref.dynamics.conv
+    with torch.no_grad():
+        for name, x, parts in (("repr", img, (r.conv1[0], list(r.conv2), r.conv3[0])), ("dyn", x10, (d[0], [d[2], d[3], d[4]], d[5]))):
+            got = eng._tower_hip(name, x).float()
+            want = _ref_tower(x, *parts)
+            assert got.shape == want.shape == (n, 8, 8, 8)
+            scale = want.abs().max().item()
+            err = (got - want).abs()
+            # accumulation order differs (MFMA vs MIOpen fp32), so a value sitting on a bf16 rounding boundary may
+            # land one ulp away and propagate: bounded by a few bf16 ulps (2^-8 relative) of the tensor's scale
+            assert scale > 0.1 and err.max().item() <= 0.03 * scale, (name, err.max().item(), scale)
+            assert (err <= 0.004 * scale).float().mean().item() > 0.97, name
+    # whole engine: same outputs as the MIOpen bf16 path within bf16 noise
+    mi = InferenceEngine(net, n, torch.bfloat16, tower="miopen")
+    for a, b in ((eng.initial(img), mi.initial(img)), (eng.recurrent(x10), mi.recurrent(x10))):
+        for u, v, nm in zip(a, b, ("value", "policy", "hidden")):
+            assert u.shape == v.shape and u.dtype == v.dtype and u.is_contiguous()
+            assert (u.float() - v.float()).abs().max().item() <= 6e-2 * max(1.0, v.float().abs().max().item()), nm
+
+
+def test_hip_tower_weight_publish():
+    """load_weights repacks the tower images in place (pointers unchanged, new results)"""
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(1)
+    eng = InferenceEngine(Network(), 8, torch.bfloat16, tower="hip")
+    x10 = torch.rand(8, 10, 8, 8, device="cuda").to(torch.bfloat16)
+    h0 = eng.recurrent(x10)[2].clone()
+    ptrs = {k: v["w_mid"].data_ptr() for k, v in eng._packs.items()}
+    torch.manual_seed(2)
+    new = Network()
+    eng.load_weights(new.state_dict())
+    assert ptrs == {k: v["w_mid"].data_ptr() for k, v in eng._packs.items()}
+    h1 = eng.recurrent(x10)[2]
+    fresh = InferenceEngine(new, 8, torch.bfloat16, tower="hip")
+    assert not torch.equal(h0, h1) and torch.equal(h1, fresh.recurrent(x10)[2])
