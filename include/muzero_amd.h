@@ -304,6 +304,22 @@ typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muz
  * hidden_dtype (MZ_BF16 or MZ_F32).  One workgroup per 4 boards. */
 int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream);
 
+/* Prediction heads (network.py:79-111) fused behind the tower: 1x1 conv 8->2 + ReLU + Flatten +
+ * Linear(128,128) + ReLU + Linear(128,65) + Softmax (policy); 1x1 conv 8->2 + ReLU + Flatten +
+ * Linear(128,1) + Tanh (value).  f32 weights and arithmetic; Linear matrices TRANSPOSED ([in][out]). */
+typedef struct mz_heads_weights {
+    const float *pc_w, *pc_b;   /* policy_head.0: [2][8], [2] */
+    const float *p1_wt, *p1_b;  /* policy_head.3: [128 in][128 out], [128] */
+    const float *p2_wt, *p2_b;  /* policy_head.5: [128 in][65 out], [65] */
+    const float *vc_w, *vc_b;   /* value_head.0: [2][8], [2] */
+    const float *v1_w, *v1_b;   /* value_head.3: [128], [1] */
+} mz_heads_weights;
+
+/* network.initial_inference / recurrent_inference (network.py:146-163) in ONE launch: tower + heads.
+ * Outputs the tuple the search consumes: value (n) f32, policy (n,65) f32 softmaxed, hidden (n,8,8,8). */
+int mz_inference_forward(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, void *hidden,
+                         int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

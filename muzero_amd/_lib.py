@@ -45,6 +45,11 @@ class TowerWeights(C.Structure):
                 ("w_last", C.c_void_p), ("b_last", C.c_void_p), ("cin", C.c_int32)]
 
 
+class HeadsWeights(C.Structure):
+    """mz_heads_weights -- f32 device pointers of the prediction heads"""
+    _fields_ = [(k, C.c_void_p) for k in ("pc_w", "pc_b", "p1_wt", "p1_b", "p2_wt", "p2_b", "vc_w", "vc_b", "v1_w", "v1_b")]
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "muzero_amd: %s is missing. Build it with `make -C muzero_amd/csrc` (or "
@@ -79,6 +84,7 @@ SIGNATURES = {
     "mz_select_action": [_p, _p, _i32, _p, _p, _i64, _p],
     "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
     "mz_tower_forward": [C.POINTER(TowerWeights), _p, _p, _i32, _i64, _p],
+    "mz_inference_forward": [C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _p, _p, _i32, _p, _p, _i64, _p],
     "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }

@@ -2,8 +2,9 @@
 //
 // Replaces, for bf16 serving, the per-layer PyTorch/MIOpen calls of network.py:49-77
 // (Representation) and network.py:113-135 (Dynamics): 3x3 conv Cin->128 + ReLU, three residual
-// blocks relu(x + conv(relu(conv(x)))) (network.py:35-47), 3x3 conv 128->8 + ReLU.  The prediction
-// heads (network.py:79-111) stay in PyTorch.
+// blocks relu(x + conv(relu(conv(x)))) (network.py:35-47), 3x3 conv 128->8 + ReLU -- and, behind it in
+// the same launch, the prediction heads (network.py:79-111), so one kernel returns the whole
+// (value, policy, hidden) tuple of initial_inference / recurrent_inference (network.py:146-163).
 //
 // Why one kernel.  An 8x8 board with 128 channels is 16 KB in bf16, so FOUR boards (256 positions,
 // the GEMM M dimension) and both activation tensors a residual block needs fit in the 160 KB LDS of
@@ -55,6 +56,16 @@ struct Tower {
     const uint4 *w_last;   // [18][32 co (8 real)][8 slots][8] bf16, same swizzle
     const float *b_last;   // [8] or null
     int cin;               // real input planes (9 or 10)
+};
+
+// prediction heads (network.py:79-111), f32 weights, FC matrices stored [in][out] so lanes (= outputs) read coalesced
+struct Heads {
+    const float *pc_w, *pc_b;    // policy 1x1 conv [2][8], [2]
+    const float *p1_wt, *p1_b;   // Linear(128,128) as [in 128][out 128], [128]
+    const float *p2_wt, *p2_b;   // Linear(128,65)  as [in 128][out 65],  [65]
+    const float *vc_w, *vc_b;    // value 1x1 conv [2][8], [2]
+    const float *v1_w, *v1_b;    // Linear(128,1) [128], [1]
+    float *value, *policy;       // outputs (n), (n,65); null = heads off
 };
 
 __device__ __forceinline__ int act_key(int q) { return (((q >> 3) & 1) << 3) | (q & 7); }
@@ -270,7 +281,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 // LDS at once (T + stage buffers = 96 KB free); wave w owns positions 32w .. 32w+31. -------------------
 template <int OUT_DT>
 __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid,
-                                           uint32_t vm) {
+                                           uint32_t vm, float (&hv)[4]) {
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     char *wl = lds + OFF_T;
     for (int i = tid; i < LAST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wl + i * 16) = tw.w_last[i];
@@ -297,21 +308,86 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
     }
     // rows co = (reg & 3) + 8 (reg >> 2) + 4 h: the 8 real planes are registers 0..3 of both lane halves
     const int64_t b = board0 + (w >> 1);
-    if (b < n_boards) {
-        const int cell = 32 * (w & 1) + r;
+    const int cell = 32 * (w & 1) + r;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int co = 4 * h + k;
-            const float v = fmaxf(acc[k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
+    for (int k = 0; k < 4; ++k) {
+        const int co = 4 * h + k;
+        const float v = fmaxf(acc[k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
+        const uint32_t vb = bf16_rne(v);
+        hv[k] = OUT_DT == MZ_F32 ? v : bf16_up(vb);  // what the heads see = what is stored
+        if (b < n_boards) {
             const int64_t o = b * 512 + co * 64 + cell;
             if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = v;
-            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)bf16_rne(v);
+            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)vb;
+        }
+    }
+}
+
+// ---- prediction heads for the tile's 4 boards (network.py:79-111), fp32 VALU; ~100k MACs per tile ------
+// LDS (the X image is dead by now): hid [4][8][64] f32, fp / fv [4][128], h1 [4][128], logit [4][65+], vpart [8]
+__device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const float (&hv)[4], int64_t board0, int64_t n_boards, int tid) {
+    float *hid = reinterpret_cast<float *>(lds + OFF_X);
+    float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *logit = h1 + 4 * 128, *vpart = logit + 4 * 80;
+    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    __syncthreads();  // every wave is done reading X
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hid[(w >> 1) * 512 + (4 * h + k) * 64 + 32 * (w & 1) + r] = hv[k];
+    __syncthreads();
+    const int b = tid >> 7, k = tid & 127;  // board of the tile, feature / output index; b is wave-uniform
+    {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8))
+        const int c2 = k >> 6, pos = k & 63;
+        float ap = hd.pc_b[c2], av = hd.vc_b[c2];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float x = hid[b * 512 + c * 64 + pos];
+            ap += hd.pc_w[c2 * 8 + c] * x;
+            av += hd.vc_w[c2 * 8 + c] * x;
+        }
+        fp[b * 128 + k] = fmaxf(ap, 0.0f);
+        fv[b * 128 + k] = fmaxf(av, 0.0f);
+    }
+    __syncthreads();
+    {   // Linear(128,128) + ReLU; value Linear(128,1) as a wave reduction
+        float a = hd.p1_b[k];
+        const float *f = fp + b * 128;
+#pragma unroll 8
+        for (int i = 0; i < 128; ++i) a += hd.p1_wt[i * 128 + k] * f[i];
+        h1[b * 128 + k] = fmaxf(a, 0.0f);
+        float v = hd.v1_w[k] * fv[b * 128 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) vpart[w] = v;
+    }
+    __syncthreads();
+    if (k < 65) {   // Linear(128,65)
+        float a = hd.p2_b[k];
+        const float *f = h1 + b * 128;
+#pragma unroll 8
+        for (int i = 0; i < 128; ++i) a += hd.p2_wt[i * 65 + k] * f[i];
+        logit[b * 80 + k] = a;
+    }
+    __syncthreads();
+    if (w < 4 && board0 + w < n_boards) {   // softmax over 65 (one wave per board), tanh
+        const float x = logit[w * 80 + lane], x64 = logit[w * 80 + 64];
+        float m = fmaxf(x, x64);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float e = expf(x - m), e64 = expf(x64 - m);
+        float sum = e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        sum += e64;
+        float *pol = hd.policy + (board0 + w) * MZ_ACTIONS;
+        pol[lane] = e / sum;
+        if (lane == 0) {
+            pol[64] = e64 / sum;
+            hd.value[board0 + w] = tanhf(vpart[2 * w] + vpart[2 * w + 1] + hd.v1_b[0]);
         }
     }
 }
 
 template <int OUT_DT>
-__global__ void __launch_bounds__(512) k_tower(Tower tw, const uint16_t *__restrict__ x, void *__restrict__ hidden, int64_t n_boards) {
+__global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_t *__restrict__ x, void *__restrict__ hidden, int64_t n_boards) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const uint32_t vm = halo_mask(tid & 31);
@@ -324,24 +400,43 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, const uint16_t *__restr
         layer_mid<false>(lds, OFF_X, OFF_T, w0, tw.b_mid + (2 * blk) * 128, tid, vm);      // t = relu(conv(x))
         layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm);   // x = relu(x + conv(t))
     }
-    layer_last<OUT_DT>(lds, tw, hidden, board0, n_boards, tid, vm);
+    float hv[4];
+    layer_last<OUT_DT>(lds, tw, hidden, board0, n_boards, tid, vm, hv);
+    if (hd.policy) heads_tile(lds, hd, hv, board0, n_boards, tid);
 }
 
 }  // namespace
 
-extern "C" int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream) {
-    MZ_REQUIRE(w, "mz_tower_forward: null weights");
-    MZ_REQUIRE(n >= 0, "mz_tower_forward: n < 0");
+static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,
+                        int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream) {
+    MZ_REQUIRE(w, "%s: null weights", who);
+    MZ_REQUIRE(n >= 0, "%s: n < 0", who);
     if (n == 0) return MZ_OK;
-    MZ_REQUIRE(w->w_first && w->w_mid && w->b_mid && w->w_last && x && hidden, "mz_tower_forward: null pointer");
-    MZ_REQUIRE(w->cin >= 1 && w->cin <= 16, "mz_tower_forward: cin %d outside [1, 16]", w->cin);
-    MZ_REQUIRE(hidden_dtype == MZ_BF16 || hidden_dtype == MZ_F32, "mz_tower_forward: hidden dtype must be bf16 or f32");
+    MZ_REQUIRE(w->w_first && w->w_mid && w->b_mid && w->w_last && x && hidden, "%s: null pointer", who);
+    MZ_REQUIRE(w->cin >= 1 && w->cin <= 16, "%s: cin %d outside [1, 16]", who, w->cin);
+    MZ_REQUIRE(hidden_dtype == MZ_BF16 || hidden_dtype == MZ_F32, "%s: hidden dtype must be bf16 or f32", who);
     MZ_REQUIRE((((uintptr_t)w->w_first | (uintptr_t)w->w_mid | (uintptr_t)w->w_last | (uintptr_t)w->b_mid | (uintptr_t)w->b_first) & 15) == 0,
-               "mz_tower_forward: weight pointers must be 16-byte aligned");
+               "%s: weight pointers must be 16-byte aligned", who);
     Tower tw{(const uint4 *)w->w_first, w->b_first, (const uint4 *)w->w_mid, w->b_mid, (const uint4 *)w->w_last, w->b_last, w->cin};
+    Heads hd{};
+    if (hw) {
+        MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_wt && hw->p1_b && hw->p2_wt && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,
+                   "%s: null head pointer", who);
+        hd = Heads{hw->pc_w, hw->pc_b, hw->p1_wt, hw->p1_b, hw->p2_wt, hw->p2_b, hw->vc_w, hw->vc_b, hw->v1_w, hw->v1_b, value, policy};
+    }
     const dim3 grid((unsigned)((n + TILE_BOARDS - 1) / TILE_BOARDS)), block(512);
-    if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, tw, (const uint16_t *)x, hidden, n);
-    else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, tw, (const uint16_t *)x, hidden, n);
+    if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, tw, hd, (const uint16_t *)x, hidden, n);
+    else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, tw, hd, (const uint16_t *)x, hidden, n);
     MZ_LAUNCH_CHECK("k_tower");
     return MZ_OK;
+}
+
+extern "C" int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream) {
+    return launch_tower("mz_tower_forward", w, nullptr, x, hidden, hidden_dtype, nullptr, nullptr, n, stream);
+}
+
+extern "C" int mz_inference_forward(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, void *hidden, int32_t hidden_dtype,
+                                    float *value, float *policy, int64_t n, void *stream) {
+    MZ_REQUIRE(heads, "mz_inference_forward: null heads");
+    return launch_tower("mz_inference_forward", w, heads, x, hidden, hidden_dtype, value, policy, n, stream);
 }

@@ -213,12 +213,27 @@ class InferenceEngine:
         return {"repr": (r.conv1[0], list(r.conv2), r.conv3[0], config.state_shape[0]),
                 "dyn": (d[0], [d[2], d[3], d[4]], d[5], HIDDEN_PLANES + 2)}
 
+    def _pack_heads(self):
+        """prediction heads (network.py:79-111) as the f32 arrays of mz_heads_weights (Linear matrices transposed)"""
+        ph, vh = self.net.prediction.policy_head, self.net.prediction.value_head
+        f = lambda t: t.detach().float().contiguous()  # noqa: E731
+        return dict(pc_w=f(ph[0].weight.reshape(2, 8)), pc_b=f(ph[0].bias), p1_wt=f(ph[3].weight.t()), p1_b=f(ph[3].bias),
+                    p2_wt=f(ph[5].weight.t()), p2_b=f(ph[5].bias), vc_w=f(vh[0].weight.reshape(2, 8)), vc_b=f(vh[0].bias),
+                    v1_w=f(vh[3].weight.reshape(128)), v1_b=f(vh[3].bias))
+
     def _repack(self):
         """(re)build the prepacked weight images IN PLACE (a captured hipGraph holds their addresses)"""
         L = self._L
+        heads = self._pack_heads()
+        if "heads" not in self._packs:
+            heads["struct"] = L.HeadsWeights(*[heads[k].data_ptr() for k, _ in L.HeadsWeights._fields_])
+            self._packs["heads"] = heads
+        else:
+            for k, t in heads.items():
+                self._packs["heads"][k].copy_(t)
         for name, (first, blocks, last, cin) in self._tower_parts().items():
             new = pack_tower(first, blocks, last, self.device, cin)
-            if name not in self._packs:
+            if name not in self._packs:  # noqa: SIM102
                 ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
                 new["struct"] = L.TowerWeights(ptr(new["w_first"]), ptr(new["b_first"]), ptr(new["w_mid"]), ptr(new["b_mid"]),
                                                ptr(new["w_last"]), ptr(new["b_last"]), new["cin"])
@@ -236,6 +251,21 @@ class InferenceEngine:
         hidden = torch.empty((x.shape[0], HIDDEN_PLANES, 8, 8), dtype=torch.bfloat16, device=x.device)
         L.call("mz_tower_forward", L.C.byref(pk["struct"]), L.dptr(x), L.dptr(hidden), L.MZ_BF16, x.shape[0], L.current_stream())
         return hidden
+
+    def _infer_hip(self, name, x):
+        """tower + prediction heads in one launch (mz_inference_forward) -> (value, policy, hidden)"""
+        L = self._L
+        pk = self._packs[name]
+        x = x.contiguous()
+        if x.dtype != torch.bfloat16 or tuple(x.shape[1:]) != (pk["cin"], 8, 8):
+            raise L.MzError("HIP tower input must be a bf16 (n,%d,8,8) tensor" % pk["cin"])
+        n = x.shape[0]
+        hidden = torch.empty((n, HIDDEN_PLANES, 8, 8), dtype=torch.bfloat16, device=x.device)
+        value = torch.empty(n, dtype=torch.float32, device=x.device)
+        policy = torch.empty((n, config.action_space_size), dtype=torch.float32, device=x.device)
+        L.call("mz_inference_forward", L.C.byref(pk["struct"]), L.C.byref(self._packs["heads"]["struct"]), L.dptr(x), L.dptr(hidden),
+               L.MZ_BF16, L.dptr(value), L.dptr(policy), n, L.current_stream())
+        return value, policy, hidden
 
     @torch.no_grad()
     def load_weights(self, state_dict):
@@ -296,8 +326,12 @@ class InferenceEngine:
 
     @torch.no_grad()
     def initial(self, image):
+        if self.tower == "hip":
+            return self._infer_hip("repr", image.to(self.dtype))
         return self._finish(self._hidden_initial(image.to(self.dtype)))
 
     @torch.no_grad()
     def recurrent(self, x10):
+        if self.tower == "hip":
+            return self._infer_hip("dyn", x10)
         return self._finish(self._hidden_recurrent(x10))

@@ -101,6 +101,29 @@ def test_hip_tower_vs_torch_fp32_reference(n):
             assert (u.float() - v.float()).abs().max().item() <= 6e-2 * max(1.0, v.float().abs().max().item()), nm
 
 
+def test_hip_heads_vs_torch_fp32_reference():
+    """mz_inference_forward: value / policy from the fused heads equal the fp32 module heads applied to the SAME hidden"""
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(5)
+    net = Network()
+    with torch.no_grad():
+        for p in net.prediction.parameters():
+            p.mul_(3.0)   # spread the logits: a near-uniform softmax would hide indexing errors
+    for n in (4096, 203, 1):
+        eng = InferenceEngine(net, n, torch.bfloat16, tower="hip")
+        x10 = torch.rand(n, 10, 8, 8, device="cuda").to(torch.bfloat16)
+        value, policy, hidden = eng.recurrent(x10)
+        assert value.shape == (n,) and policy.shape == (n, 65) and hidden.shape == (n, 8, 8, 8) and hidden.dtype == torch.bfloat16
+        assert torch.equal(hidden, eng._tower_hip("dyn", x10))
+        ref = Network().cuda()
+        ref.load_state_dict({k: v.to(torch.bfloat16).float() for k, v in net.state_dict().items()})   # the bf16-rounded weights
+        with torch.no_grad():
+            p_ref, v_ref = ref.prediction(hidden.float())
+        assert (policy - p_ref).abs().max().item() < 2e-5 and (value - v_ref.reshape(-1)).abs().max().item() < 2e-5
+        assert (policy.sum(1) - 1).abs().max().item() < 1e-5
+        assert policy.std().item() > 1e-3
+
+
 def test_hip_tower_weight_publish():
     """load_weights repacks the tower images in place (pointers unchanged, new results)"""
     from muzero_amd.network import InferenceEngine, Network
@@ -108,11 +131,12 @@ def test_hip_tower_weight_publish():
     eng = InferenceEngine(Network(), 8, torch.bfloat16, tower="hip")
     x10 = torch.rand(8, 10, 8, 8, device="cuda").to(torch.bfloat16)
     h0 = eng.recurrent(x10)[2].clone()
-    ptrs = {k: v["w_mid"].data_ptr() for k, v in eng._packs.items()}
+    ptrs = {k: v.get("w_mid", v.get("p1_wt")).data_ptr() for k, v in eng._packs.items()}
     torch.manual_seed(2)
     new = Network()
     eng.load_weights(new.state_dict())
-    assert ptrs == {k: v["w_mid"].data_ptr() for k, v in eng._packs.items()}
-    h1 = eng.recurrent(x10)[2]
+    assert ptrs == {k: v.get("w_mid", v.get("p1_wt")).data_ptr() for k, v in eng._packs.items()} and len(ptrs) == 3
+    v1, p1, h1 = eng.recurrent(x10)
     fresh = InferenceEngine(new, 8, torch.bfloat16, tower="hip")
-    assert not torch.equal(h0, h1) and torch.equal(h1, fresh.recurrent(x10)[2])
+    vf, pf, hf = fresh.recurrent(x10)
+    assert not torch.equal(h0, h1) and torch.equal(h1, hf) and torch.equal(v1, vf) and torch.equal(p1, pf)
