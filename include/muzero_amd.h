@@ -292,12 +292,17 @@ int mz_bias_act_nhwc(void *y, const void *bias, const void *residual, int64_t n_
 typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muzero_amd.network.pack_tower) */
     const void *w_first;   /* bf16 [9 taps][128 co][16 ci]      conv1 / dynamics conv.0, ci zero-padded; tap = ky*3+kx */
     const float *b_first;  /* f32 [128] or NULL (Dynamics' first conv has no bias, network.py:119) */
-    const void *w_mid;     /* bf16 [6 layers][18 stages][128 co][8 slots][8]: stage = tap*2 + (ci >= 64),
-                              16-byte chunk c of the 64 input channels stored in slot c ^ ((co >> 1) & 7) */
+    const void *w_mid;     /* bf16 [6 layers][36 stages][128 co][4 slots][8]: stage = tap*4 + ci/32,
+                              16-byte chunk c of the 32 input channels stored in slot c ^ ((co >> 2) & 3);
+                              followed by 4 stages (32 KB) of padding: the weight stream prefetches 4 stages ahead */
     const float *b_mid;    /* f32 [6][128] */
-    const void *w_last;    /* bf16 [18 stages][32 co (rows 8..31 zero)][8 slots][8], same chunk swizzle */
+    const void *w_last;    /* bf16 [18 stages][32 co (rows 8..31 zero)][8 slots][8]: stage = tap*2 + ci/64,
+                              chunk c of the 64 input channels in slot c ^ ((co >> 1) & 7) */
     const float *b_last;   /* f32 [8] or NULL (network.py:127) */
     int32_t cin;           /* input planes: 9 (Representation) or 10 (Dynamics: hidden ++ action planes) */
+    int64_t *debug_stamps; /* diagnostics, normally NULL: device array [ceil(n/4)][24] receiving s_memtime stamps at the
+                              kernel's phase boundaries (0 start, 1 first layer, 2 weight prologue, 3+2l / 4+2l K loop /
+                              epilogue of mid layer l, 15 last layer, 16 heads) */
 } mz_tower_weights;
 
 /* x: (n,cin,8,8) bf16 NCHW (e.g. the net_in rows mz_mcts_select writes); hidden: (n,8,8,8) NCHW of

@@ -42,7 +42,7 @@ class Replay(C.Structure):
 class TowerWeights(C.Structure):
     """mz_tower_weights -- device pointers to the prepacked tower weights"""
     _fields_ = [("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
-                ("w_last", C.c_void_p), ("b_last", C.c_void_p), ("cin", C.c_int32)]
+                ("w_last", C.c_void_p), ("b_last", C.c_void_p), ("cin", C.c_int32), ("debug_stamps", C.c_void_p)]
 
 
 class HeadsWeights(C.Structure):

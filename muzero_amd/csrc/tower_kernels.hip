@@ -21,13 +21,13 @@
 //   (bias, residual, ReLU, bf16 rounding) writes 8-byte pieces straight back into the [pos][ch] LDS
 //   image the next layer reads -- no transpose, no shuffle.
 //   wave w: co half (w & 1) x board (w >> 1)  ->  2 x 2 accumulator tiles of 32 x 32 per wave.
-//   K loop: 9 taps x 2 half-channel chunks = 18 stages of [128 co][64 ci]; one barrier per stage;
-//   stage s+1 is fetched into registers while stage s computes (register-staged, written to the
-//   other LDS buffer before the barrier).
-//   The 3x3 halo is handled by masking: a lane whose shifted position leaves the board gets a zero
-//   fragment (v_cndmask), so the activation image needs no padding ring.
+//   K loop: 9 taps x 4 channel quarters = 36 stages of [128 co][32 ci] through a ring of three 8 KB
+//   LDS buffers; one barrier per stage, and fragment reads run one k-step ahead ACROSS the barrier
+//   (layer_mid), so the MFMA stream never drains at a stage boundary.
+//   The 3x3 halo needs no padding ring in the activation image: a lane whose shifted position leaves
+//   the board reads its fragment from a block of zeros instead.
 // LDS images are XOR-swizzled in 16-byte chunks so every ds_read_b128 lane group hits 16 distinct
-// 4-bank slots: activations  slot = chunk ^ ((y & 1) << 3 | x),  weights  slot = chunk ^ ((co >> 1) & 7).
+// 4-bank slots: activations  slot = chunk ^ ((y & 1) << 3 | x),  weights (64-byte rows)  slot = chunk ^ ((co >> 2) & 3).
 // Weights arrive PREPACKED in exactly these images (muzero_amd/network.py: pack_tower), so staging
 // is a linear copy.
 #include "common.h"
@@ -41,21 +41,25 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int TILE_BOARDS = 4;
 constexpr int TILE_POS = 256;
 constexpr int ACT_BYTES = TILE_POS * 128 * 2;  // 65,536: one [256 pos][128 ch] bf16 image
-constexpr int WSTAGE_BYTES = 128 * 64 * 2;     // 16,384: one [128 co][64 ci] weight stage
+constexpr int WSTAGE_BYTES = 128 * 32 * 2;     // 8,192: one [128 co][32 ci] weight stage
 constexpr int OFF_X = 0, OFF_T = ACT_BYTES, OFF_W = 2 * ACT_BYTES;
-constexpr int LDS_BYTES = 2 * ACT_BYTES + 2 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
-constexpr int N_STAGES = 18;
+constexpr int OFF_Z = OFF_W + 3 * WSTAGE_BYTES;              // 256 bytes of zeros (the halo's fragment)
+constexpr int OFF_B = OFF_Z + 256;                           // biases f32 [7][128]: first layer, six mid layers (3,584 B)
+constexpr int LDS_BYTES = 2 * ACT_BYTES + 4 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
+constexpr int N_STAGES = 36;                   // 9 taps x 4 quarters of the input channels
+constexpr int LAST_STAGES = 18;                // last layer: 9 taps x 2 halves, [32 co][64 ci] each
 constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
-constexpr int LAST_W_BYTES = N_STAGES * 32 * 64 * 2;  // 73,728
+constexpr int LAST_W_BYTES = 18 * 32 * 64 * 2;  // 73,728
 
 struct Tower {
     const uint4 *w_first;  // [9][128 co][16 ci] bf16
     const float *b_first;  // [128] or null
-    const uint4 *w_mid;    // [6][18][128 co][8 slots][8] bf16, slot = chunk ^ ((co >> 1) & 7)
+    const uint4 *w_mid;    // [6][36][128 co][4 slots][8] bf16, slot = chunk ^ ((co >> 2) & 3); + 4 stages of padding
     const float *b_mid;    // [6][128]
     const uint4 *w_last;   // [18][32 co (8 real)][8 slots][8] bf16, same swizzle
     const float *b_last;   // [8] or null
     int cin;               // real input planes (9 or 10)
+    long long *stamps;     // diagnostics: [blocks][24] s_memtime stamps at the phase boundaries (null = off)
 };
 
 // prediction heads (network.py:79-111), f32 weights, FC matrices stored [in][out] so lanes (= outputs) read coalesced
@@ -75,6 +79,12 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {  // finite inputs (post-
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_up(uint32_t v) { return __uint_as_float(v << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 
 // validity of (tap, position tile j) for this lane: bit tap*2+j.  Position tile j of a board covers
 // rows 4j..4j+3; the lane's cell is row 4j + (r >> 3), column r & 7.
@@ -94,18 +104,49 @@ __device__ __forceinline__ uint32_t halo_mask(int r) {
     return m;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ bf16x8 lds_frag(const char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
-__device__ __forceinline__ bf16x8 zero_frag() {
-    bf16x8 z;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.0f;
-    return z;
+// fragment ANDed with an all-ones / all-zeros lane mask: the branch-free halo (a select on the loaded
+// value makes hipcc branch around it and wait lgkmcnt(0) inside the branch)
+__device__ __forceinline__ bf16x8 lds_frag_masked(const char *p, unsigned keep) {
+    u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+    v &= keep;
+    return __builtin_bit_cast(bf16x8, v);
 }
+__device__ __forceinline__ unsigned keep_word(uint32_t vm, int bit) { return 0u - ((vm >> bit) & 1u); }
 
 // ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
+// K loop: 36 stages of [128 co][32 ci] weights (8 KB; 2 k-steps of 16 channels = 8 MFMAs per wave)
+// through a ring of THREE LDS buffers, software-pipelined one whole stage deep:
+//   iteration i, after barrier B_i:  write stage i+2 to the ring (from registers, fetched two
+//   iterations ago), issue the global load of stage i+4, read the 8 fragments of stage i+1 into the
+//   other fragment set, and run the 8 MFMAs of stage i on the set read during iteration i-1.
+// B_i orders "all waves finished stage i-1" (buffer (i+2)%3 = (i-1)%3 is free) and "all waves wrote
+// stage i+1" (in iteration i-1), so stage i+1 is readable anywhere in iteration i.  Nothing an MFMA
+// consumes was requested less than a stage ago, and the barrier's lgkmcnt(0) finds its reads done.
+// The weight stream is one contiguous array over all six layers (+ 4 stages of padding): it simply
+// keeps running across layer boundaries, so only the first layer pays a prologue (mid_prologue).
+// Halo: a lane whose shifted position leaves the board reads its fragment from a 256-byte block of
+// zeros (OFF_Z) instead -- the select is on the ADDRESS, once per tap, so nothing waits on the data.
+struct Frags { bf16x8 a[2][2], b[2][2]; };  // [kk][i] weights, [kk][j] activations of one stage
+
+__device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict__ wp, int tid, uint4 &g0, uint4 &g1) {
+    const uint4 s0 = wp[tid], s1 = wp[512 + tid];
+    g0 = wp[2 * 512 + tid];
+    g1 = wp[3 * 512 + tid];
+    *reinterpret_cast<uint4 *>(lds + OFF_W + tid * 16) = s0;
+    *reinterpret_cast<uint4 *>(lds + OFF_W + WSTAGE_BYTES + tid * 16) = s1;
+    __syncthreads();
+}
+
+#define MZ_STAMP(tw, k)                                                                              \
+    do {                                                                                             \
+        if ((tw).stamps && threadIdx.x == 0) (tw).stamps[(int64_t)blockIdx.x * 24 + (k)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+
 template <bool RES>
-__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-                                          int tid, uint32_t vm) {
+__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, int bias_off,
+                                          int tid, uint32_t vm, uint4 &g0, uint4 &g1, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
     f32x16 acc[2][2];
@@ -116,60 +157,105 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
 
-    // stage 0 -> buffer 0
-    uint4 st0 = wp[tid], st1 = wp[tid + 512];
-    *reinterpret_cast<uint4 *>(lds + OFF_W + tid * 16) = st0;
-    *reinterpret_cast<uint4 *>(lds + OFF_W + (tid + 512) * 16) = st1;
-    __syncthreads();
-
-    int wrow[2], wkey[2];
+    char *wring = lds + OFF_W;
+    // weights: address = ring buffer + wrow + ((2 kk) ^ h ^ wkey) << 4 = ring + wrow + ((kk * 32) ^ wk4)
+    int wrow[2], wk4[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int co = cobase + 32 * i + r;
-        wrow[i] = co * 128;
-        wkey[i] = (co >> 1) & 7;
+        wrow[i] = co * 64;
+        wk4[i] = (h ^ ((co >> 2) & 3)) << 4;
     }
-    const char *src = lds + src_off;
-
-#pragma unroll
-    for (int s = 0; s < N_STAGES; ++s) {
-        const int tap = s >> 1, kc = s & 1;
-        const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
-        if (s + 1 < N_STAGES) {
-            st0 = wp[(s + 1) * 1024 + tid];
-            st1 = wp[(s + 1) * 1024 + tid + 512];
-        }
-        const char *wb = lds + OFF_W + (s & 1) * WSTAGE_BYTES;
-        int arow[2], akey[2];
+    // activations per tap: row base (or the zero block) and (h ^ key) << 4
+    int arow[2], ak4[2];
+    auto set_tap = [&](int ky, int kx) {   // tap = 3 ky + kx
+        const int dq = (ky - 1) * 8 + (kx - 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q2 = (posbase + 32 * j + r + dq) & 255;
-            arow[j] = q2 * 256;
-            akey[j] = act_key(q2);
+            const bool ok = (vm >> ((ky * 3 + kx) * 2 + j)) & 1u;
+            arow[j] = ok ? src_off + q2 * 256 : OFF_Z;
+            ak4[j] = (h ^ act_key(q2)) << 4;
         }
+    };
+    // the 8 fragments of stage st (its tap set by the caller): ring buffer st % 3, channel quarter st & 3
+    auto load_stage = [&](int st, Frags &f) {
+        const char *wb = wring + (st % 3) * WSTAGE_BYTES;
+        const int kq = st & 3;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 a[2], b[2];
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = lds_frag(wb + wrow[i] + (((kk * 2 + h) ^ wkey[i]) << 4));
+            for (int i = 0; i < 2; ++i) f.a[kk][i] = lds_frag(wb + wrow[i] + ((kk * 32) ^ wk4[i]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                b[j] = lds_frag(src + arow[j] + (((kc * 8 + kk * 2 + h) ^ akey[j]) << 4));
-                if (tap != 4 && !((vm >> (tap * 2 + j)) & 1u)) b[j] = zero_frag();
+            for (int j = 0; j < 2; ++j) f.b[kk][j] = lds_frag(lds + arow[j] + (((kq * 4 + kk * 2) << 4) ^ ak4[j]));
+        }
+    };
+
+    Frags fr[2];
+    set_tap(0, 0);
+    load_stage(0, fr[0]);
+    u32x4 ga = __builtin_bit_cast(u32x4, g0), gb = __builtin_bit_cast(u32x4, g1);   // stages st + 2 / st + 3 in flight (even / odd stage)
+
+    // 3 trips x 12 stages (3 taps): stage % 3, stage & 3 and the register-set parity are compile-time constants and
+    // the body is branch-free.  The last trip prefetches "tap 9" (every lane on the zero block) and stages 36..39 (the
+    // next layer's first stages, or the padding): harmless, and no tail conditions.
+#pragma unroll 1
+    for (int T = 0; T < 3; ++T) {
+        const uint4 *wt = wp + (T * 12 + 4) * 512 + tid;
+#pragma unroll
+        for (int ss = 0; ss < 12; ++ss) {
+            // raw barrier: LDS traffic only (__syncthreads() would also drain vmcnt, i.e. the weight fetches in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // hand-ordered issue, fenced with sched_barrier(0) (hipcc otherwise sinks the prefetch reads to their use and
+            // exposes every stage to the LDS latency): an MFMA first, so the matrix pipe restarts right behind the barrier;
+            // the ring write + weight fetch; then two fragment reads of stage st+1 behind each of the next four MFMAs; the
+            // last MFMAs cover those reads' latency before the next barrier's lgkmcnt(0).
+            const Frags &c = fr[ss & 1];
+            Frags &nx = fr[(ss + 1) & 1];
+            const char *wb = wring + ((ss + 1) % 3) * WSTAGE_BYTES;   // 12 = 0 (mod 3, mod 4, mod 2): ss + 1 indexes like st + 1
+            const int kq = (ss + 1) & 3;
+#define MZ_MFMA(kk, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.a[kk][i], c.b[kk][j], acc[i][j], 0, 0, 0)
+#define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
+            MZ_MFMA(0, 0, 0);
+            MZ_FENCE();
+            {
+                u32x4 *slot = reinterpret_cast<u32x4 *>(wring + ((ss + 2) % 3) * WSTAGE_BYTES + tid * 16);   // stage st + 2 leaves its
+                const u32x4 fresh = *reinterpret_cast<const u32x4 *>(wt + ss * 512);                          // registers, st + 4 takes them
+                if (ss & 1) { *slot = gb; gb = fresh; }
+                else { *slot = ga; ga = fresh; }
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
+            nx.a[0][0] = lds_frag(wb + wrow[0] + wk4[0]);
+            nx.a[0][1] = lds_frag(wb + wrow[1] + wk4[1]);
+            MZ_FENCE();
+            MZ_MFMA(0, 0, 1);
+            MZ_FENCE();
+            nx.b[0][0] = lds_frag(lds + arow[0] + ((kq * 64) ^ ak4[0]));
+            nx.b[0][1] = lds_frag(lds + arow[1] + ((kq * 64) ^ ak4[1]));
+            MZ_FENCE();
+            MZ_MFMA(0, 1, 0);
+            MZ_FENCE();
+            nx.a[1][0] = lds_frag(wb + wrow[0] + (32 ^ wk4[0]));
+            nx.a[1][1] = lds_frag(wb + wrow[1] + (32 ^ wk4[1]));
+            MZ_FENCE();
+            MZ_MFMA(0, 1, 1);
+            MZ_FENCE();
+            nx.b[1][0] = lds_frag(lds + arow[0] + ((kq * 64 + 32) ^ ak4[0]));
+            nx.b[1][1] = lds_frag(lds + arow[1] + ((kq * 64 + 32) ^ ak4[1]));
+            MZ_FENCE();
+            MZ_MFMA(1, 0, 0);
+            MZ_MFMA(1, 0, 1);
+            MZ_MFMA(1, 1, 0);
+            MZ_MFMA(1, 1, 1);
+            MZ_FENCE();
+#undef MZ_MFMA
+#undef MZ_FENCE
         }
-        if (s + 1 < N_STAGES) {
-            char *nb = lds + OFF_W + ((s + 1) & 1) * WSTAGE_BYTES;
-            *reinterpret_cast<uint4 *>(nb + tid * 16) = st0;
-            *reinterpret_cast<uint4 *>(nb + (tid + 512) * 16) = st1;
-        }
-        __syncthreads();
     }
 
+    g0 = __builtin_bit_cast(uint4, ga);
+    g1 = __builtin_bit_cast(uint4, gb);
+    MZ_STAMP(tw, stamp_id);
     // epilogue: lane = position, registers 4g..4g+3 = channels co0..co0+3
     char *dst = lds + dst_off;
 #pragma unroll
@@ -177,8 +263,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
-            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + co0);
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bias_off + co0 * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
@@ -196,8 +281,8 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.0f);
                 uint2 o;
-                o.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
-                o.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+                o.x = pack_bf16(v[0], v[1]);
+                o.y = pack_bf16(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(p) = o;
             }
         }
@@ -245,8 +330,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q2 = (posbase + 32 * j + r + dq) & 255;
-            b[j] = lds_frag(in + q2 * 32 + h * 16);
-            if (tap != 4 && !((vm >> (tap * 2 + j)) & 1u)) b[j] = zero_frag();
+            b[j] = lds_frag_masked(in + q2 * 32 + h * 16, keep_word(vm, tap * 2 + j));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -259,8 +343,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
-            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (tw.b_first) bv = *reinterpret_cast<const f32x4 *>(tw.b_first + co0);
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + OFF_B + co0 * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
@@ -269,8 +352,8 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][j][4 * g + k] + bv[k], 0.0f);
                 uint2 o;
-                o.x = bf16_rne(v[0]) | (bf16_rne(v[1]) << 16);
-                o.y = bf16_rne(v[2]) | (bf16_rne(v[3]) << 16);
+                o.x = pack_bf16(v[0], v[1]);
+                o.y = pack_bf16(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(p) = o;
             }
         }
@@ -292,17 +375,16 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
     const char *src = lds + OFF_X;
     const int jt = w & 1, wkey = (r >> 1) & 7;
 #pragma unroll
-    for (int s = 0; s < N_STAGES; ++s) {
+    for (int s = 0; s < LAST_STAGES; ++s) {
         const int tap = s >> 1, kc = s & 1;
         const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
         const int q2 = (32 * w + r + dq) & 255;
         const int arow = q2 * 256, akey = act_key(q2);
-        const bool ok = tap == 4 || ((vm >> (tap * 2 + jt)) & 1u);
+        const unsigned keep = keep_word(vm, tap * 2 + jt);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bf16x8 a = lds_frag(wl + s * 4096 + r * 128 + (((kk * 2 + h) ^ wkey) << 4));
-            bf16x8 b = lds_frag(src + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4));
-            if (!ok) b = zero_frag();
+            const bf16x8 b = lds_frag_masked(src + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4), keep);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     }
@@ -324,51 +406,80 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
 }
 
 // ---- prediction heads for the tile's 4 boards (network.py:79-111), fp32 VALU; ~100k MACs per tile ------
-// LDS (the X image is dead by now): hid [4][8][64] f32, fp / fv [4][128], h1 [4][128], logit [4][65+], vpart [8]
+// Latency, not arithmetic, is the cost here (every weight comes from L2), so: both Linear layers split
+// their 128 inputs over the four 128-thread groups (thread = one output column x 32 inputs x all 4
+// boards), ALL 64 weights a thread needs are requested up front (two batches in flight while the 1x1
+// convolutions run), and the partial sums meet in LDS.
+// LDS (the X image is dead by now), floats: hid [4][8][64] | fp [4][128] | fv [4][128] | h1 [4][128] |
+// part [4 groups][4 boards][128] | vsum [4]
 __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const float (&hv)[4], int64_t board0, int64_t n_boards, int tid) {
     float *hid = reinterpret_cast<float *>(lds + OFF_X);
-    float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *logit = h1 + 4 * 128, *vpart = logit + 4 * 80;
+    float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *part = h1 + 4 * 128, *vsum = part + 4 * 4 * 128;
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int grp = tid >> 7, k = tid & 127;   // input group / board (wave-uniform), output column
+    float w1[32], w2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w1[i] = hd.p1_wt[(32 * grp + i) * 128 + k];
+    const int k2 = k < MZ_ACTIONS ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w2[i] = hd.p2_wt[(32 * grp + i) * MZ_ACTIONS + k2];
     __syncthreads();  // every wave is done reading X
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hid[(w >> 1) * 512 + (4 * h + k) * 64 + 32 * (w & 1) + r] = hv[k];
+    for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * h + q) * 64 + 32 * (w & 1) + r] = hv[q];
     __syncthreads();
-    const int b = tid >> 7, k = tid & 127;  // board of the tile, feature / output index; b is wave-uniform
-    {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8))
+    {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); here grp = board
         const int c2 = k >> 6, pos = k & 63;
         float ap = hd.pc_b[c2], av = hd.vc_b[c2];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float x = hid[b * 512 + c * 64 + pos];
+            const float x = hid[grp * 512 + c * 64 + pos];
             ap += hd.pc_w[c2 * 8 + c] * x;
             av += hd.vc_w[c2 * 8 + c] * x;
         }
-        fp[b * 128 + k] = fmaxf(ap, 0.0f);
-        fv[b * 128 + k] = fmaxf(av, 0.0f);
+        fp[grp * 128 + k] = fmaxf(ap, 0.0f);
+        fv[grp * 128 + k] = fmaxf(av, 0.0f);
     }
     __syncthreads();
-    {   // Linear(128,128) + ReLU; value Linear(128,1) as a wave reduction
-        float a = hd.p1_b[k];
-        const float *f = fp + b * 128;
-#pragma unroll 8
-        for (int i = 0; i < 128; ++i) a += hd.p1_wt[i * 128 + k] * f[i];
-        h1[b * 128 + k] = fmaxf(a, 0.0f);
-        float v = hd.v1_w[k] * fv[b * 128 + k];
+    {   // Linear(128,128): partial sums over inputs 32 grp .. 32 grp + 31, all 4 boards
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) vpart[w] = v;
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 *f = reinterpret_cast<const f32x4 *>(fp + b * 128 + 32 * grp);
+            float a = 0.0f;
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const f32x4 x = f[i4];
+                a += w1[4 * i4] * x[0] + w1[4 * i4 + 1] * x[1] + w1[4 * i4 + 2] * x[2] + w1[4 * i4 + 3] * x[3];
+            }
+            part[(grp * 4 + b) * 128 + k] = a;
+        }
+        if (w < 4) {   // value Linear(128,1): wave w = board w
+            float v = hd.v1_w[lane] * fv[w * 128 + lane] + hd.v1_w[lane + 64] * fv[w * 128 + lane + 64];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) vsum[w] = v;
+        }
     }
     __syncthreads();
-    if (k < 65) {   // Linear(128,65)
-        float a = hd.p2_b[k];
-        const float *f = h1 + b * 128;
-#pragma unroll 8
-        for (int i = 0; i < 128; ++i) a += hd.p2_wt[i * 65 + k] * f[i];
-        logit[b * 80 + k] = a;
+    h1[grp * 128 + k] = fmaxf(hd.p1_b[k] + part[(0 * 4 + grp) * 128 + k] + part[(1 * 4 + grp) * 128 + k] + part[(2 * 4 + grp) * 128 + k] +
+                                  part[(3 * 4 + grp) * 128 + k], 0.0f);   // here grp = board
+    __syncthreads();
+    if (k < MZ_ACTIONS) {   // Linear(128,65) partial sums
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4 *f = reinterpret_cast<const f32x4 *>(h1 + b * 128 + 32 * grp);
+            float a = 0.0f;
+#pragma unroll
+            for (int i4 = 0; i4 < 8; ++i4) {
+                const f32x4 x = f[i4];
+                a += w2[4 * i4] * x[0] + w2[4 * i4 + 1] * x[1] + w2[4 * i4 + 2] * x[2] + w2[4 * i4 + 3] * x[3];
+            }
+            part[(grp * 4 + b) * 128 + k] = a;
+        }
     }
     __syncthreads();
     if (w < 4 && board0 + w < n_boards) {   // softmax over 65 (one wave per board), tanh
-        const float x = logit[w * 80 + lane], x64 = logit[w * 80 + 64];
+        auto logit = [&](int a) { return hd.p2_b[a] + part[(0 * 4 + w) * 128 + a] + part[(1 * 4 + w) * 128 + a] + part[(2 * 4 + w) * 128 + a] + part[(3 * 4 + w) * 128 + a]; };
+        const float x = logit(lane), x64 = logit(64);
         float m = fmaxf(x, x64);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -381,7 +492,7 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const flo
         pol[lane] = e / sum;
         if (lane == 0) {
             pol[64] = e64 / sum;
-            hd.value[board0 + w] = tanhf(vpart[2 * w] + vpart[2 * w + 1] + hd.v1_b[0]);
+            hd.value[board0 + w] = tanhf(vsum[w] + hd.v1_b[0]);
         }
     }
 }
@@ -392,17 +503,33 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     const int tid = threadIdx.x;
     const uint32_t vm = halo_mask(tid & 31);
     const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
+    if (tid < 16) *reinterpret_cast<uint4 *>(lds + OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);  // visible after layer_first's barriers
+    {   // biases -> LDS (7 x 128 f32): the epilogues then never wait on L2
+        float *bl = reinterpret_cast<float *>(lds + OFF_B);
+        if (tid < 128) bl[tid] = tw.b_first ? tw.b_first[tid] : 0.0f;
+        bl[128 + tid] = tw.b_mid[tid];
+        if (tid < 256) bl[640 + tid] = tw.b_mid[512 + tid];
+    }
+    MZ_STAMP(tw, 0);
     layer_first(lds, tw, x, board0, n_boards, tid, vm);
+    MZ_STAMP(tw, 1);
+    uint4 g0, g1;
+    mid_prologue(lds, tw.w_mid, tid, g0, g1);
+    MZ_STAMP(tw, 2);
 #pragma unroll 1
     for (int blk = 0; blk < 3; ++blk) {
-        const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 1024;
-        const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 1024;
-        layer_mid<false>(lds, OFF_X, OFF_T, w0, tw.b_mid + (2 * blk) * 128, tid, vm);      // t = relu(conv(x))
-        layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm);   // x = relu(x + conv(t))
+        const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 512;
+        const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 512;
+        layer_mid<false>(lds, OFF_X, OFF_T, w0, OFF_B + (1 + 2 * blk) * 512, tid, vm, g0, g1, tw, 3 + 4 * blk);      // t = relu(conv(x))
+        MZ_STAMP(tw, 4 + 4 * blk);
+        layer_mid<true>(lds, OFF_T, OFF_X, w1, OFF_B + (2 + 2 * blk) * 512, tid, vm, g0, g1, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
+        MZ_STAMP(tw, 6 + 4 * blk);
     }
     float hv[4];
     layer_last<OUT_DT>(lds, tw, hidden, board0, n_boards, tid, vm, hv);
+    MZ_STAMP(tw, 15);
     if (hd.policy) heads_tile(lds, hd, hv, board0, n_boards, tid);
+    MZ_STAMP(tw, 16);
 }
 
 }  // namespace
@@ -417,7 +544,8 @@ static int launch_tower(const char *who, const mz_tower_weights *w, const mz_hea
     MZ_REQUIRE(hidden_dtype == MZ_BF16 || hidden_dtype == MZ_F32, "%s: hidden dtype must be bf16 or f32", who);
     MZ_REQUIRE((((uintptr_t)w->w_first | (uintptr_t)w->w_mid | (uintptr_t)w->w_last | (uintptr_t)w->b_mid | (uintptr_t)w->b_first) & 15) == 0,
                "%s: weight pointers must be 16-byte aligned", who);
-    Tower tw{(const uint4 *)w->w_first, w->b_first, (const uint4 *)w->w_mid, w->b_mid, (const uint4 *)w->w_last, w->b_last, w->cin};
+    Tower tw{(const uint4 *)w->w_first, w->b_first, (const uint4 *)w->w_mid, w->b_mid, (const uint4 *)w->w_last, w->b_last, w->cin,
+             (long long *)w->debug_stamps};
     Heads hd{};
     if (hw) {
         MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_wt && hw->p1_b && hw->p2_wt && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,

@@ -123,25 +123,26 @@ class Network(nn.Module):
         return self.steps
 
 
-def _swizzle_rows(w):
-    """(rows, 64 ci) -> (rows, 8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ ((co >> 1) & 7) -- the LDS
-    image tower_kernels.hip reads conflict-free (XOR is an involution, so slot s holds chunk s ^ key)"""
-    rows = w.shape[0]
-    ch = w.reshape(rows, 8, 8)
-    key = (torch.arange(rows, device=w.device) >> 1) & 7
-    idx = torch.arange(8, device=w.device).unsqueeze(0) ^ key.unsqueeze(1)      # (rows, 8): chunk held by each slot
-    return torch.gather(ch, 1, idx.unsqueeze(-1).expand(rows, 8, 8))
+def _swizzle_rows(w, shift):
+    """(rows, C ci) -> (rows, C/8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ ((co >> shift) & (C/8 - 1)) -- the
+    LDS image tower_kernels.hip reads conflict-free (XOR is an involution, so slot s holds chunk s ^ key)"""
+    rows, nch = w.shape[0], w.shape[1] // 8
+    ch = w.reshape(rows, nch, 8)
+    key = (torch.arange(rows, device=w.device) >> shift) & (nch - 1)
+    idx = torch.arange(nch, device=w.device).unsqueeze(0) ^ key.unsqueeze(1)      # (rows, nch): chunk held by each slot
+    return torch.gather(ch, 1, idx.unsqueeze(-1).expand(rows, nch, 8))
 
 
-def _pack_stages(w, rows):
-    """conv weight (co, 128, 3, 3) -> (18 stages, rows, 8, 8): stage = (ky*3+kx)*2 + (ci >= 64), co zero-padded to rows"""
+def _pack_stages(w, rows, cchunk, shift):
+    """conv weight (co, 128, 3, 3) -> (9 * 128/cchunk stages, rows, cchunk/8, 8): stage = (ky*3+kx) * (128/cchunk) + ci/cchunk,
+    co zero-padded to rows"""
     co = w.shape[0]
     out = []
     for tap in range(9):
-        for kc in range(2):
-            blk = torch.zeros((rows, 64), dtype=w.dtype, device=w.device)
-            blk[:co] = w[:, kc * 64:(kc + 1) * 64, tap // 3, tap % 3]
-            out.append(_swizzle_rows(blk))
+        for kc in range(128 // cchunk):
+            blk = torch.zeros((rows, cchunk), dtype=w.dtype, device=w.device)
+            blk[:co] = w[:, kc * cchunk:(kc + 1) * cchunk, tap // 3, tap % 3]
+            out.append(_swizzle_rows(blk, shift))
     return torch.stack(out)
 
 
@@ -158,11 +159,11 @@ def pack_tower(first, blocks, last, device, cin):
     mids, bmid = [], []
     for blk in blocks:
         for conv in (blk.block[0], blk.block[2]):
-            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128))
+            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128, 32, 2))
             bmid.append(conv.bias.detach().float().cpu())
     return dict(w_first=wf.to(bf).to(device).contiguous(), b_first=None if first.bias is None else f32(first.bias, 128),
-                w_mid=torch.stack(mids).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),
-                w_last=_pack_stages(last.weight.detach().float().cpu(), 32).to(bf).to(device).contiguous(),
+                w_mid=torch.cat([torch.stack(mids).reshape(-1), torch.zeros(4 * 128 * 32)]).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),
+                w_last=_pack_stages(last.weight.detach().float().cpu(), 32, 64, 1).to(bf).to(device).contiguous(),
                 b_last=None if last.bias is None else f32(last.bias, 8), cin=int(cin))
 
 
@@ -236,7 +237,7 @@ class InferenceEngine:
             if name not in self._packs:  # noqa: SIM102
                 ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
                 new["struct"] = L.TowerWeights(ptr(new["w_first"]), ptr(new["b_first"]), ptr(new["w_mid"]), ptr(new["b_mid"]),
-                                               ptr(new["w_last"]), ptr(new["b_last"]), new["cin"])
+                                               ptr(new["w_last"]), ptr(new["b_last"]), new["cin"], None)
                 self._packs[name] = new
             else:
                 for k, t in new.items():

@@ -22,7 +22,7 @@ def timeit(fn, it=20):
 torch.manual_seed(0)
 net = Network()
 x = torch.rand(B, 10, 8, 8, device="cuda").to(torch.bfloat16)
-for tower in ("hip", "miopen"):
+for tower in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("hip", "miopen")):
     eng = InferenceEngine(net, B, torch.bfloat16, tower=tower)
     ms_t = timeit(lambda: eng._hidden_recurrent(x))
     ms = timeit(lambda: eng.recurrent(x))

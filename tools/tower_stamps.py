@@ -1,0 +1,28 @@
+"""per-phase cycle breakdown of the tower kernel from its in-kernel s_memtime stamps:
+   python tools/tower_stamps.py [batch]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from muzero_amd.network import Network, InferenceEngine
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+torch.manual_seed(0)
+eng = InferenceEngine(Network(), B, torch.bfloat16, tower="hip")
+x = torch.rand(B, 10, 8, 8, device="cuda").to(torch.bfloat16)
+for _ in range(5):
+    eng.recurrent(x)
+nb = (B + 3) // 4
+st = torch.zeros((nb, 24), dtype=torch.int64, device="cuda")
+eng._packs["dyn"]["struct"].debug_stamps = st.data_ptr()
+eng.recurrent(x)
+torch.cuda.synchronize()
+eng._packs["dyn"]["struct"].debug_stamps = None
+s = st.cpu().double()
+names = ["first layer", "weight prologue"] + [n for l in range(6) for n in ("mid %d K loop" % l, "mid %d epilogue" % l)] + ["last layer", "heads"]
+d = s[:, 1:17] - s[:, 0:16]
+tot = (s[:, 16] - s[:, 0])
+print("s_memtime ticks (100 MHz constant clock on gfx950? compare total with wall): blocks %d" % nb)
+for i, n in enumerate(names):
+    print("%-18s mean %9.0f  min %9.0f  max %9.0f   %5.1f %%" % (n, d[:, i].mean(), d[:, i].min(), d[:, i].max(), 100 * d[:, i].mean() / tot.mean()))
+print("%-18s mean %9.0f" % ("total per block", tot.mean()))
+print("kernel span (max end - min start): %.0f ticks" % (s[:, 16].max() - s[:, 0].min()))
