@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libmuzero_amd.so")
+LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(HERE, "lib", "libmuzero_amd.so")  # override: experiment builds
 
 MZ_F32, MZ_BF16, MZ_F16 = 0, 1, 2
 ST_OK, ST_ILLEGAL, ST_DONE = 0, 1, 2

@@ -43,9 +43,9 @@ constexpr int TILE_POS = 256;
 constexpr int ACT_BYTES = TILE_POS * 128 * 2;  // 65,536: one [256 pos][128 ch] bf16 image
 constexpr int WSTAGE_BYTES = 128 * 32 * 2;     // 8,192: one [128 co][32 ci] weight stage
 constexpr int OFF_X = 0, OFF_T = ACT_BYTES, OFF_W = 2 * ACT_BYTES;
-constexpr int OFF_Z = OFF_W + 3 * WSTAGE_BYTES;              // 256 bytes of zeros (the halo's fragment)
-constexpr int OFF_B = OFF_Z + 256;                           // biases f32 [7][128]: first layer, six mid layers (3,584 B)
 constexpr int LDS_BYTES = 2 * ACT_BYTES + 4 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
+constexpr int OFF_Z = LDS_BYTES;  // the halo's zero fragment: a DS read at or beyond the workgroup's LDS allocation returns 0
+                                  // (hardware bounds check; the allocation is the whole 160 KB, so nothing lies behind it)
 constexpr int N_STAGES = 36;                   // 9 taps x 4 quarters of the input channels
 constexpr int LAST_STAGES = 18;                // last layer: 9 taps x 2 halves, [32 co][64 ci] each
 constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
@@ -115,9 +115,17 @@ __device__ __forceinline__ bf16x8 lds_frag_masked(const char *p, unsigned keep) 
 }
 __device__ __forceinline__ unsigned keep_word(uint32_t vm, int bit) { return 0u - ((vm >> bit) & 1u); }
 
+// one weight stage (8 KB) global -> LDS by LDS-DMA: each of the 8 waves moves 1 KB with ONE instruction
+// (lane-linear: LDS address = wave-uniform base + 16 * lane), no VGPRs, no ds_write.  The packed image is
+// already in LDS order, so the source is linear too.
+__device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restrict__ stage, int tid) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(stage + tid),
+                                     (__attribute__((address_space(3))) void *)(ring_buf + (tid >> 6) * 1024), 16, 0, 0);
+}
+
 // ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
 // K loop: 36 stages of [128 co][32 ci] weights (8 KB; 2 k-steps of 16 channels = 8 MFMAs per wave)
-// through a ring of THREE LDS buffers, software-pipelined one whole stage deep:
+// through a ring of FOUR LDS buffers filled by LDS-DMA, software-pipelined one whole stage deep:
 //   iteration i, after barrier B_i:  write stage i+2 to the ring (from registers, fetched two
 //   iterations ago), issue the global load of stage i+4, read the 8 fragments of stage i+1 into the
 //   other fragment set, and run the 8 MFMAs of stage i on the set read during iteration i-1.
@@ -130,12 +138,11 @@ __device__ __forceinline__ unsigned keep_word(uint32_t vm, int bit) { return 0u 
 // zeros (OFF_Z) instead -- the select is on the ADDRESS, once per tap, so nothing waits on the data.
 struct Frags { bf16x8 a[2][2], b[2][2]; };  // [kk][i] weights, [kk][j] activations of one stage
 
-__device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict__ wp, int tid, uint4 &g0, uint4 &g1) {
-    const uint4 s0 = wp[tid], s1 = wp[512 + tid];
-    g0 = wp[2 * 512 + tid];
-    g1 = wp[3 * 512 + tid];
-    *reinterpret_cast<uint4 *>(lds + OFF_W + tid * 16) = s0;
-    *reinterpret_cast<uint4 *>(lds + OFF_W + WSTAGE_BYTES + tid * 16) = s1;
+__device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict__ wp, int tid) {
+    dma_stage(lds + OFF_W, wp, tid);
+    dma_stage(lds + OFF_W + WSTAGE_BYTES, wp + 512, tid);
+    dma_stage(lds + OFF_W + 2 * WSTAGE_BYTES, wp + 2 * 512, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
@@ -145,10 +152,16 @@ __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict_
     } while (0)
 
 template <bool RES>
-__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, int bias_off,
-                                          int tid, uint32_t vm, uint4 &g0, uint4 &g1, const Tower &tw, int stamp_id) {
+__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, const float *__restrict__ bias,
+                                          int tid, uint32_t vm, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
+    // the lane's 32 bias values, requested now and first touched in the epilogue (the barrier asm below pins the loads here)
+    f32x4 bv[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[i][g] = *reinterpret_cast<const f32x4 *>(bias + cobase + 32 * i + 8 * g + 4 * h);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -180,7 +193,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     };
     // the 8 fragments of stage st (its tap set by the caller): ring buffer st % 3, channel quarter st & 3
     auto load_stage = [&](int st, Frags &f) {
-        const char *wb = wring + (st % 3) * WSTAGE_BYTES;
+        const char *wb = wring + (st & 3) * WSTAGE_BYTES;
         const int kq = st & 3;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -194,36 +207,32 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     Frags fr[2];
     set_tap(0, 0);
     load_stage(0, fr[0]);
-    u32x4 ga = __builtin_bit_cast(u32x4, g0), gb = __builtin_bit_cast(u32x4, g1);   // stages st + 2 / st + 3 in flight (even / odd stage)
 
     // 3 trips x 12 stages (3 taps): stage % 3, stage & 3 and the register-set parity are compile-time constants and
     // the body is branch-free.  The last trip prefetches "tap 9" (every lane on the zero block) and stages 36..39 (the
     // next layer's first stages, or the padding): harmless, and no tail conditions.
 #pragma unroll 1
     for (int T = 0; T < 3; ++T) {
-        const uint4 *wt = wp + (T * 12 + 4) * 512 + tid;
+        const uint4 *wt = wp + (T * 12 + 3) * 512;
 #pragma unroll
         for (int ss = 0; ss < 12; ++ss) {
             // raw barrier: LDS traffic only (__syncthreads() would also drain vmcnt, i.e. the weight fetches in flight)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifndef MZ_EXP_NOBARRIER
+            // all but the youngest DMA (stage st + 2, issued one iteration ago) have landed: stage st + 1 is complete
+            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             // hand-ordered issue, fenced with sched_barrier(0) (hipcc otherwise sinks the prefetch reads to their use and
             // exposes every stage to the LDS latency): an MFMA first, so the matrix pipe restarts right behind the barrier;
             // the ring write + weight fetch; then two fragment reads of stage st+1 behind each of the next four MFMAs; the
             // last MFMAs cover those reads' latency before the next barrier's lgkmcnt(0).
             const Frags &c = fr[ss & 1];
             Frags &nx = fr[(ss + 1) & 1];
-            const char *wb = wring + ((ss + 1) % 3) * WSTAGE_BYTES;   // 12 = 0 (mod 3, mod 4, mod 2): ss + 1 indexes like st + 1
+            const char *wb = wring + ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
             const int kq = (ss + 1) & 3;
 #define MZ_MFMA(kk, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.a[kk][i], c.b[kk][j], acc[i][j], 0, 0, 0)
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
             MZ_MFMA(0, 0, 0);
             MZ_FENCE();
-            {
-                u32x4 *slot = reinterpret_cast<u32x4 *>(wring + ((ss + 2) % 3) * WSTAGE_BYTES + tid * 16);   // stage st + 2 leaves its
-                const u32x4 fresh = *reinterpret_cast<const u32x4 *>(wt + ss * 512);                          // registers, st + 4 takes them
-                if (ss & 1) { *slot = gb; gb = fresh; }
-                else { *slot = ga; ga = fresh; }
-            }
             if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
             nx.a[0][0] = lds_frag(wb + wrow[0] + wk4[0]);
             nx.a[0][1] = lds_frag(wb + wrow[1] + wk4[1]);
@@ -240,21 +249,30 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
             MZ_FENCE();
             MZ_MFMA(0, 1, 1);
             MZ_FENCE();
+#ifdef MZ_EXP_FEWREADS
+            nx.b[1][0] = nx.b[0][0];
+            nx.b[1][1] = nx.b[0][1];
+#else
             nx.b[1][0] = lds_frag(lds + arow[0] + ((kq * 64 + 32) ^ ak4[0]));
             nx.b[1][1] = lds_frag(lds + arow[1] + ((kq * 64 + 32) ^ ak4[1]));
+#endif
             MZ_FENCE();
             MZ_MFMA(1, 0, 0);
             MZ_MFMA(1, 0, 1);
             MZ_MFMA(1, 1, 0);
             MZ_MFMA(1, 1, 1);
             MZ_FENCE();
+            // the weight DMA costs its issuing wave ~60-180 cycles: issue it LAST, while this wave's four MFMAs above
+            // drain and before it would wait at the barrier anyway
+#ifndef MZ_EXP_NOWEIGHTS
+            dma_stage(wring + ((ss + 3) & 3) * WSTAGE_BYTES, wt + ss * 512, tid);   // stage st + 3 -> the buffer stage st - 1 left
+#endif
+            MZ_FENCE();
 #undef MZ_MFMA
 #undef MZ_FENCE
         }
     }
 
-    g0 = __builtin_bit_cast(uint4, ga);
-    g1 = __builtin_bit_cast(uint4, gb);
     MZ_STAMP(tw, stamp_id);
     // epilogue: lane = position, registers 4g..4g+3 = channels co0..co0+3
     char *dst = lds + dst_off;
@@ -263,14 +281,13 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + bias_off + co0 * 4);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
                 char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
                 float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] + bv[k];
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] + bv[i][g][k];
                 if (RES) {
                     const uint2 x = *reinterpret_cast<const uint2 *>(p);
                     v[0] += bf16_up(x.x & 0xFFFFu);
@@ -343,7 +360,8 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(lds + OFF_B + co0 * 4);
+            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (tw.b_first) bv = *reinterpret_cast<const f32x4 *>(tw.b_first + co0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
@@ -503,26 +521,18 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     const int tid = threadIdx.x;
     const uint32_t vm = halo_mask(tid & 31);
     const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
-    if (tid < 16) *reinterpret_cast<uint4 *>(lds + OFF_Z + tid * 16) = make_uint4(0, 0, 0, 0);  // visible after layer_first's barriers
-    {   // biases -> LDS (7 x 128 f32): the epilogues then never wait on L2
-        float *bl = reinterpret_cast<float *>(lds + OFF_B);
-        if (tid < 128) bl[tid] = tw.b_first ? tw.b_first[tid] : 0.0f;
-        bl[128 + tid] = tw.b_mid[tid];
-        if (tid < 256) bl[640 + tid] = tw.b_mid[512 + tid];
-    }
     MZ_STAMP(tw, 0);
     layer_first(lds, tw, x, board0, n_boards, tid, vm);
     MZ_STAMP(tw, 1);
-    uint4 g0, g1;
-    mid_prologue(lds, tw.w_mid, tid, g0, g1);
+    mid_prologue(lds, tw.w_mid, tid);
     MZ_STAMP(tw, 2);
 #pragma unroll 1
     for (int blk = 0; blk < 3; ++blk) {
         const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 512;
         const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 512;
-        layer_mid<false>(lds, OFF_X, OFF_T, w0, OFF_B + (1 + 2 * blk) * 512, tid, vm, g0, g1, tw, 3 + 4 * blk);      // t = relu(conv(x))
+        layer_mid<false>(lds, OFF_X, OFF_T, w0, tw.b_mid + (2 * blk) * 128, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
         MZ_STAMP(tw, 4 + 4 * blk);
-        layer_mid<true>(lds, OFF_T, OFF_X, w1, OFF_B + (2 + 2 * blk) * 512, tid, vm, g0, g1, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
+        layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
     float hv[4];
