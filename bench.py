@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2]): 4096 game trees per GPU x 50 simulations, random-init MuZero
-network (seed 1261), PyTorch-ROCm inference once per simulation on the whole leaf batch, roots =
+network (seed 1261), bf16 inference once per simulation on the whole leaf batch, roots =
 positions reached after 0..59 random moves.  One "step" = one complete search of every tree on the
 rank: initial inference + root expansion with Dirichlet noise + 50 x (recurrent inference + fused
 expand/backup/select kernel) + root statistics.  Inputs are resident in HBM before the timed region.
@@ -16,7 +16,8 @@ Extra legs, reported in the same JSON line and NOT part of `value`:
   env        configs[1]: 1,048,576 random-play games x 60 steps; fused in-register playout kernel
              and the HBM-resident step kernel (roofline_env is for the latter)
   selfplay   --selfplay-games G: G whole games of 60 moves through the batched engine -> games/s
-  roofline   dominant hand-written kernel of the timed region (k_backup_select), HIP-event timed
+  roofline   dominant kernel of the timed region: k_tower (conv tower + heads, MFMA bound), HIP-event timed;
+             roofline_tree = k_backup_select and roofline_env = k_env_step (both HBM bound)
   cpu_baseline  the C oracle (tree search) + PyTorch CPU inference on the host cores, bounded sample
 """
 import argparse
@@ -33,7 +34,10 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
 F32_PEAK_TFLOPS = 157.3
-NET_MFLOP = 116.0            # MFLOP per inference sample
+NET_MFLOP = 116.0            # MFLOP per inference sample (rounded)
+# exact algorithmic FLOPs of one recurrent_inference sample (network.py:113-135, 79-111), real channel counts:
+# conv 10->128 + 6 x conv 128->128 + conv 128->8 (3x3 on 64 cells, 2 FLOP per MAC) + heads (2 x 1x1 conv 8->2, 128x128, 128x65, 128x1)
+TOWER_FLOP = 2 * 64 * 9 * (10 * 128 + 6 * 128 * 128 + 128 * 8) + 2 * (2 * 2 * 8 * 64 + 128 * 128 + 128 * 65 + 128)
 ENV_BYTES_PER_STEP = 46
 
 
@@ -46,6 +50,7 @@ def parse():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tower", default="auto", choices=["auto", "hip", "miopen"], help="inference path (auto = hip for bf16)")
     ap.add_argument("--env-games", type=int, default=1 << 20)
     ap.add_argument("--selfplay-games", type=int, default=1024)
     ap.add_argument("--selfplay-sims", type=int, default=50)
@@ -237,7 +242,7 @@ def main():
 
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
     torch.manual_seed(1261)  # main.py:18: identical random-init weights on every rank
-    net = InferenceEngine(Network(), args.trees, dtype)
+    net = InferenceEngine(Network(), args.trees, dtype, tower=args.tower)
     n, S = args.trees, args.sims
     eng = SelfPlayEngine(n, net, num_simulations=S, device=device, use_graph=not args.no_graph, seed=1261 + rank)
     from muzero_amd.shard import game_block, max_over_ranks
@@ -270,8 +275,10 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %d game trees per GPU x %d simulations per search; random-init MuZero net "
-                               "(seed 1261), PyTorch-ROCm %s inference on the whole leaf batch; roots = positions after 0..59 "
-                               "random moves; tree arithmetic f64/f32 as the reference" % (n, S, args.dtype),
+                               "(seed 1261), %s inference on the whole leaf batch once per simulation (%s); roots = positions after "
+                               "0..59 random moves; tree arithmetic f64/f32 as the reference" %
+                               (n, S, args.dtype, "one HIP launch: LDS-resident MFMA conv tower + heads" if getattr(net, "tower", "") == "hip"
+                                else "PyTorch-ROCm / MIOpen"),
                    "trees_per_gpu": n, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "games sharded x%d" % world},
     }
 
@@ -315,20 +322,27 @@ def main():
         hid_bytes = (2 * 512 + 512 + 640) * eb
         us = tot_ms / launches * 1e3
         gbps = n * (tree_bytes + hid_bytes) / (us * 1e-6) / 1e9
-        out["roofline"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "us_per_launch": us,
-                           "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
-                           "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes)}
-        # ---- inference share: the same S-1 recurrent calls alone
-        ms_net = event_time_ms(lambda: net.recurrent(eng.mcts.net_in), 20)
-        tf = n * NET_MFLOP * 1e6 / (ms_net * 1e-3) / 1e12
+        out["roofline_tree"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "us_per_launch": us,
+                                "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
+                                "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes),
+                                "share_of_step": us * 1e-3 / (dt / args.steps / S * 1e3)}
+        # ---- the dominant kernel of the timed region: the inference launch (k_tower: conv tower + heads, ~97 % of a
+        # simulation step), HIP-event timed back to back on the launch stream; MFMA bound
+        ms_net = event_time_ms(lambda: net.recurrent(eng.mcts.net_in), 50)
         peak = F32_PEAK_TFLOPS if dtype == torch.float32 else BF16_PEAK_TFLOPS
-        out["roofline_net"] = {"kernel": "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf,
-                               "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "ms_per_call": ms_net, "batch": n}
+        hip = getattr(net, "tower", "") == "hip"
+        flop = n * (TOWER_FLOP if hip else NET_MFLOP * 1e6)
+        tf = flop / (ms_net * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_tower (mz_inference_forward: LDS-resident conv tower + prediction heads)" if hip else
+                           "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf, "peak": peak,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": pmc_traffic("k_tower") if hip else None,
+                           "us_per_launch": ms_net * 1e3, "boards_per_launch": n, "flop_per_board": TOWER_FLOP if hip else NET_MFLOP * 1e6,
+                           "algorithmic_flop_per_launch": flop, "share_of_step": ms_net / (dt / args.steps / S * 1e3)}
         out.update(bench_env(args, device))
         if args.selfplay_games > 0:
             g = args.selfplay_games
-            net_sp = InferenceEngine(Network(), g, dtype)
+            net_sp = InferenceEngine(Network(), g, dtype, tower=args.tower)
             sp = SelfPlayEngine(g, net_sp, num_simulations=args.selfplay_sims, device=device, use_graph=not args.no_graph)
             sp.play_games(max_moves=2)  # warm-up: graph capture, kernel selection
             torch.cuda.synchronize()

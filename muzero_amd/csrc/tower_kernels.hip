@@ -106,14 +106,6 @@ __device__ __forceinline__ uint32_t halo_mask(int r) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ bf16x8 lds_frag(const char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
-// fragment ANDed with an all-ones / all-zeros lane mask: the branch-free halo (a select on the loaded
-// value makes hipcc branch around it and wait lgkmcnt(0) inside the branch)
-__device__ __forceinline__ bf16x8 lds_frag_masked(const char *p, unsigned keep) {
-    u32x4 v = *reinterpret_cast<const u32x4 *>(p);
-    v &= keep;
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ unsigned keep_word(uint32_t vm, int bit) { return 0u - ((vm >> bit) & 1u); }
 
 // one weight stage (8 KB) global -> LDS by LDS-DMA: each of the 8 waves moves 1 KB with ONE instruction
 // (lane-linear: LDS address = wave-uniform base + 16 * lane), no VGPRs, no ds_write.  The packed image is
@@ -138,12 +130,12 @@ __device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restric
 // zeros (OFF_Z) instead -- the select is on the ADDRESS, once per tap, so nothing waits on the data.
 struct Frags { bf16x8 a[2][2], b[2][2]; };  // [kk][i] weights, [kk][j] activations of one stage
 
+// the first three weight stages of the first mid layer: issued at kernel start (the ring is idle during the
+// first layer), complete by the __syncthreads() that ends the first layer (it drains vmcnt)
 __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict__ wp, int tid) {
     dma_stage(lds + OFF_W, wp, tid);
     dma_stage(lds + OFF_W + WSTAGE_BYTES, wp + 512, tid);
     dma_stage(lds + OFF_W + 2 * WSTAGE_BYTES, wp + 2 * 512, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 }
 
 #define MZ_STAMP(tw, k)                                                                              \
@@ -314,6 +306,14 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
     char *in = lds + OFF_T;
     char *wf = lds + OFF_T + TILE_POS * 32;
+    f32x4 bv[2][4];   // requested now, first touched in the epilogue
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bv[i][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (tw.b_first) bv[i][g] = *reinterpret_cast<const f32x4 *>(tw.b_first + cobase + 32 * i + 8 * g + 4 * h);
+        }
     {   // input: thread -> position tid & 255, channels 8*(tid >> 8) .. +7
         const int q = tid & 255, part = tid >> 8;
         const int64_t b = board0 + (q >> 6);
@@ -347,7 +347,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q2 = (posbase + 32 * j + r + dq) & 255;
-            b[j] = lds_frag_masked(in + q2 * 32 + h * 16, keep_word(vm, tap * 2 + j));
+            b[j] = lds_frag(lds + (((vm >> (tap * 2 + j)) & 1u) ? OFF_T + q2 * 32 : OFF_Z) + h * 16);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -360,15 +360,13 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
-            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (tw.b_first) bv = *reinterpret_cast<const f32x4 *>(tw.b_first + co0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
                 char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
                 float v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][j][4 * g + k] + bv[k], 0.0f);
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][j][4 * g + k] + bv[i][g][k], 0.0f);
                 uint2 o;
                 o.x = pack_bf16(v[0], v[1]);
                 o.y = pack_bf16(v[2], v[3]);
@@ -390,19 +388,17 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
     f32x16 acc;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
-    const char *src = lds + OFF_X;
     const int jt = w & 1, wkey = (r >> 1) & 7;
 #pragma unroll
     for (int s = 0; s < LAST_STAGES; ++s) {
         const int tap = s >> 1, kc = s & 1;
         const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
         const int q2 = (32 * w + r + dq) & 255;
-        const int arow = q2 * 256, akey = act_key(q2);
-        const unsigned keep = keep_word(vm, tap * 2 + jt);
+        const int arow = ((vm >> (tap * 2 + jt)) & 1u) ? OFF_X + q2 * 256 : OFF_Z, akey = act_key(q2);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bf16x8 a = lds_frag(wl + s * 4096 + r * 128 + (((kk * 2 + h) ^ wkey) << 4));
-            const bf16x8 b = lds_frag_masked(src + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4), keep);
+            const bf16x8 b = lds_frag(lds + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     }
@@ -433,6 +429,9 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
 __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const float (&hv)[4], int64_t board0, int64_t n_boards, int tid) {
     float *hid = reinterpret_cast<float *>(lds + OFF_X);
     float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *part = h1 + 4 * 128, *vsum = part + 4 * 4 * 128;
+    float *prm = vsum + 4;   // small parameters: pc_w 16 | pc_b 2 | vc_w 16 | vc_b 2 (pad to 40) | p1_b 128 | p2_b 65 (pad 72) | v1_w 128 | v1_b 1
+    float *s_pc_w = prm, *s_pc_b = prm + 16, *s_vc_w = prm + 18, *s_vc_b = prm + 34, *s_p1_b = prm + 40, *s_p2_b = prm + 168, *s_v1_w = prm + 240,
+          *s_v1_b = prm + 368;
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int grp = tid >> 7, k = tid & 127;   // input group / board (wave-uniform), output column
     float w1[32], w2[32];
@@ -441,18 +440,28 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const flo
     const int k2 = k < MZ_ACTIONS ? k : 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) w2[i] = hd.p2_wt[(32 * grp + i) * MZ_ACTIONS + k2];
+    float pv = 0.0f;   // one small parameter per thread, same request batch as the matrices above (one exposed L2 latency)
+    if (tid < 16) pv = hd.pc_w[tid];
+    else if (tid < 18) pv = hd.pc_b[tid - 16];
+    else if (tid < 34) pv = hd.vc_w[tid - 18];
+    else if (tid < 36) pv = hd.vc_b[tid - 34];
+    else if (tid >= 40 && tid < 168) pv = hd.p1_b[tid - 40];
+    else if (tid >= 168 && tid < 168 + MZ_ACTIONS) pv = hd.p2_b[tid - 168];
+    else if (tid >= 240 && tid < 368) pv = hd.v1_w[tid - 240];
+    else if (tid == 368) pv = hd.v1_b[0];
     __syncthreads();  // every wave is done reading X
+    prm[tid] = pv;
 #pragma unroll
     for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * h + q) * 64 + 32 * (w & 1) + r] = hv[q];
     __syncthreads();
     {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); here grp = board
         const int c2 = k >> 6, pos = k & 63;
-        float ap = hd.pc_b[c2], av = hd.vc_b[c2];
+        float ap = s_pc_b[c2], av = s_vc_b[c2];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float x = hid[grp * 512 + c * 64 + pos];
-            ap += hd.pc_w[c2 * 8 + c] * x;
-            av += hd.vc_w[c2 * 8 + c] * x;
+            ap += s_pc_w[c2 * 8 + c] * x;
+            av += s_vc_w[c2 * 8 + c] * x;
         }
         fp[grp * 128 + k] = fmaxf(ap, 0.0f);
         fv[grp * 128 + k] = fmaxf(av, 0.0f);
@@ -471,14 +480,14 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const flo
             part[(grp * 4 + b) * 128 + k] = a;
         }
         if (w < 4) {   // value Linear(128,1): wave w = board w
-            float v = hd.v1_w[lane] * fv[w * 128 + lane] + hd.v1_w[lane + 64] * fv[w * 128 + lane + 64];
+            float v = s_v1_w[lane] * fv[w * 128 + lane] + s_v1_w[lane + 64] * fv[w * 128 + lane + 64];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0) vsum[w] = v;
         }
     }
     __syncthreads();
-    h1[grp * 128 + k] = fmaxf(hd.p1_b[k] + part[(0 * 4 + grp) * 128 + k] + part[(1 * 4 + grp) * 128 + k] + part[(2 * 4 + grp) * 128 + k] +
+    h1[grp * 128 + k] = fmaxf(s_p1_b[k] + part[(0 * 4 + grp) * 128 + k] + part[(1 * 4 + grp) * 128 + k] + part[(2 * 4 + grp) * 128 + k] +
                                   part[(3 * 4 + grp) * 128 + k], 0.0f);   // here grp = board
     __syncthreads();
     if (k < MZ_ACTIONS) {   // Linear(128,65) partial sums
@@ -496,7 +505,7 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const flo
     }
     __syncthreads();
     if (w < 4 && board0 + w < n_boards) {   // softmax over 65 (one wave per board), tanh
-        auto logit = [&](int a) { return hd.p2_b[a] + part[(0 * 4 + w) * 128 + a] + part[(1 * 4 + w) * 128 + a] + part[(2 * 4 + w) * 128 + a] + part[(3 * 4 + w) * 128 + a]; };
+        auto logit = [&](int a) { return s_p2_b[a] + part[(0 * 4 + w) * 128 + a] + part[(1 * 4 + w) * 128 + a] + part[(2 * 4 + w) * 128 + a] + part[(3 * 4 + w) * 128 + a]; };
         const float x = logit(lane), x64 = logit(64);
         float m = fmaxf(x, x64);
 #pragma unroll
@@ -510,7 +519,7 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const flo
         pol[lane] = e / sum;
         if (lane == 0) {
             pol[64] = e64 / sum;
-            hd.value[board0 + w] = tanhf(vsum[w] + hd.v1_b[0]);
+            hd.value[board0 + w] = tanhf(vsum[w] + s_v1_b[0]);
         }
     }
 }
@@ -522,9 +531,9 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     const uint32_t vm = halo_mask(tid & 31);
     const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
     MZ_STAMP(tw, 0);
+    mid_prologue(lds, tw.w_mid, tid);
     layer_first(lds, tw, x, board0, n_boards, tid, vm);
     MZ_STAMP(tw, 1);
-    mid_prologue(lds, tw.w_mid, tid);
     MZ_STAMP(tw, 2);
 #pragma unroll 1
     for (int blk = 0; blk < 3; ++blk) {
