@@ -6,6 +6,9 @@ wrapper raises on a non-zero return code with the library's error text.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: the library must bind to the HIP runtime torch has loaded; loading it before torch
+#                              leaves two runtimes in the process and every launch fails with "no ROCm-capable device"
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(HERE, "lib", "libmuzero_amd.so")  # override: experiment builds
 
