@@ -229,12 +229,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # rehearsal of the N > 1 protocol on a one-GPU box: MZ_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL needs one device per rank); the numbers of such a run mean nothing, the code path is the real one
+    rehearsal = os.environ.get("MZ_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from muzero_amd.env import make_image
     from muzero_amd.network import InferenceEngine, Network
