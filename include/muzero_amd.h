@@ -293,7 +293,7 @@ typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muz
     const void *w_first;   /* bf16 [9 taps][128 co][16 ci]      conv1 / dynamics conv.0, ci zero-padded; tap = ky*3+kx */
     const float *b_first;  /* f32 [128] or NULL (Dynamics' first conv has no bias, network.py:119) */
     const void *w_mid;     /* bf16 [6 layers][36 stages][128 co][4 slots][8]: stage = tap*4 + ci/32,
-                              16-byte chunk c of the 32 input channels stored in slot c ^ ((co >> 2) & 3);
+                              16-byte chunk c of the 32 input channels stored in slot c ^ {0,2,3,1}[(co >> 2) & 3];
                               followed by 4 stages (32 KB) of padding: the weight stream prefetches 4 stages ahead */
     const float *b_mid;    /* f32 [6][128] */
     const void *w_last;    /* bf16 [18 stages][32 co (rows 8..31 zero)][8 slots][8]: stage = tap*2 + ci/64,

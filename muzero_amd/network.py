@@ -123,17 +123,20 @@ class Network(nn.Module):
         return self.steps
 
 
-def _swizzle_rows(w, shift):
-    """(rows, C ci) -> (rows, C/8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ ((co >> shift) & (C/8 - 1)) -- the
-    LDS image tower_kernels.hip reads conflict-free (XOR is an involution, so slot s holds chunk s ^ key)"""
+def _swizzle_rows(w, shift, perm=None):
+    """(rows, C ci) -> (rows, C/8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ key(co), key = (co >> shift) &
+    (C/8 - 1), optionally mapped through `perm` -- the LDS image tower_kernels.hip reads conflict-free (XOR is an
+    involution, so slot s holds chunk s ^ key)"""
     rows, nch = w.shape[0], w.shape[1] // 8
     ch = w.reshape(rows, nch, 8)
     key = (torch.arange(rows, device=w.device) >> shift) & (nch - 1)
+    if perm is not None:
+        key = torch.tensor(perm, device=w.device)[key]
     idx = torch.arange(nch, device=w.device).unsqueeze(0) ^ key.unsqueeze(1)      # (rows, nch): chunk held by each slot
     return torch.gather(ch, 1, idx.unsqueeze(-1).expand(rows, nch, 8))
 
 
-def _pack_stages(w, rows, cchunk, shift):
+def _pack_stages(w, rows, cchunk, shift, perm=None):
     """conv weight (co, 128, 3, 3) -> (9 * 128/cchunk stages, rows, cchunk/8, 8): stage = (ky*3+kx) * (128/cchunk) + ci/cchunk,
     co zero-padded to rows"""
     co = w.shape[0]
@@ -142,7 +145,7 @@ def _pack_stages(w, rows, cchunk, shift):
         for kc in range(128 // cchunk):
             blk = torch.zeros((rows, cchunk), dtype=w.dtype, device=w.device)
             blk[:co] = w[:, kc * cchunk:(kc + 1) * cchunk, tap // 3, tap % 3]
-            out.append(_swizzle_rows(blk, shift))
+            out.append(_swizzle_rows(blk, shift, perm))
     return torch.stack(out)
 
 
@@ -159,7 +162,7 @@ def pack_tower(first, blocks, last, device, cin):
     mids, bmid = [], []
     for blk in blocks:
         for conv in (blk.block[0], blk.block[2]):
-            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128, 32, 2))
+            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128, 32, 2, (0, 2, 3, 1)))
             bmid.append(conv.bias.detach().float().cpu())
     return dict(w_first=wf.to(bf).to(device).contiguous(), b_first=None if first.bias is None else f32(first.bias, 128),
                 w_mid=torch.cat([torch.stack(mids).reshape(-1), torch.zeros(4 * 128 * 32)]).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),

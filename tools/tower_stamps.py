@@ -9,8 +9,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 torch.manual_seed(0)
 eng = InferenceEngine(Network(), B, torch.bfloat16, tower="hip")
 x = torch.rand(B, 10, 8, 8, device="cuda").to(torch.bfloat16)
-for _ in range(5):
-    eng.recurrent(x)
+import time
+t0 = time.time()
+while time.time() - t0 < 2.0:   # the clock the chip holds under sustained load (MI355X_MICROARCH.md, DVFS item 6)
+    for _ in range(50):
+        eng.recurrent(x)
+    torch.cuda.synchronize()
 nb = (B + 3) // 4
 st = torch.zeros((nb, 24), dtype=torch.int64, device="cuda")
 eng._packs["dyn"]["struct"].debug_stamps = st.data_ptr()
@@ -25,4 +29,6 @@ print("s_memtime ticks (100 MHz constant clock on gfx950? compare total with wal
 for i, n in enumerate(names):
     print("%-18s mean %9.0f  min %9.0f  max %9.0f   %5.1f %%" % (n, d[:, i].mean(), d[:, i].min(), d[:, i].max(), 100 * d[:, i].mean() / tot.mean()))
 print("%-18s mean %9.0f" % ("total per block", tot.mean()))
+rt = (s[:, 18] - s[:, 17])
+print("in-kernel clock: %.3f GHz (shader cycles / 100 MHz real-time ticks, median over blocks)" % float((tot / rt).median() * 0.1))
 print("kernel span (max end - min start): %.0f ticks" % (s[:, 16].max() - s[:, 0].min()))
