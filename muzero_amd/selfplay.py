@@ -113,9 +113,13 @@ class SelfPlayEngine:
                 self.net.recurrent(self.mcts.net_in)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # one graph = `_graph_steps` consecutive simulation steps (every step reads what the previous one wrote, so the
+        # chain is just kernel nodes in sequence); replaying one big graph instead of S-1 small ones removes the host
+        # launch gap between steps
+        self._graph_steps = max(1, min(self.S - 1, int(getattr(self, "graph_steps", 0)) or (self.S - 1)))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._cap = self._sim_step()
+            self._cap = [self._sim_step() for _ in range(self._graph_steps)]
         self._graph = g
 
     def search(self, image, noise="auto"):
@@ -130,9 +134,13 @@ class SelfPlayEngine:
             self.mcts.select()
             if self.use_graph and S > 1:
                 self._ensure_graph()
-                for _ in range(S - 1):
+                full, rest = divmod(S - 1, self._graph_steps)
+                for _ in range(full):
                     self._graph.replay()
-                self.mcts.sims_done += S - 1
+                for _ in range(rest):   # only when graph_steps was set below S - 1
+                    v, p, h = self.net.recurrent(self.mcts.net_in)
+                    self.mcts.backup_select(v, p, h.reshape(self.n, 8, 8, 8))
+                self.mcts.sims_done += full * self._graph_steps
             else:
                 for _ in range(S - 1):
                     v, p, h = self.net.recurrent(self.mcts.net_in)
