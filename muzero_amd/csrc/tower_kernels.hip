@@ -47,16 +47,15 @@ constexpr int LDS_BYTES = 2 * ACT_BYTES + 4 * WSTAGE_BYTES;  // 163,840 = all of
 constexpr int OFF_Z = LDS_BYTES;  // the halo's zero fragment: a DS read at or beyond the workgroup's LDS allocation returns 0
                                   // (hardware bounds check; the allocation is the whole 160 KB, so nothing lies behind it)
 constexpr int N_STAGES = 36;                   // 9 taps x 4 quarters of the input channels
-constexpr int LAST_STAGES = 18;                // last layer: 9 taps x 2 halves, [32 co][64 ci] each
 constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
-constexpr int LAST_W_BYTES = 18 * 32 * 64 * 2;  // 73,728
+constexpr int LAST_W_BYTES = 36 * 16 * 32 * 2;  // 36,864
 
 struct Tower {
     const uint4 *w_first;  // [9][128 co][16 ci] bf16
     const float *b_first;  // [128] or null
     const uint4 *w_mid;    // [6][36][128 co][4 slots][8] bf16, slot = chunk ^ {0,2,3,1}[(co >> 2) & 3]; + 4 stages of padding
     const float *b_mid;    // [6][128]
-    const uint4 *w_last;   // [18][32 co (8 real)][8 slots][8] bf16, same swizzle
+    const uint4 *w_last;   // [36][16 co (8 real)][4 slots][8] bf16, same swizzle as w_mid
     const float *b_last;   // [8] or null
     int cin;               // real input planes (9 or 10)
     long long *stamps;     // diagnostics: [blocks][24] s_memtime stamps at the phase boundaries (null = off)
@@ -379,45 +378,99 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
     __syncthreads();
 }
 
-// ---- last layer: X -> hidden (global, NCHW, 8 planes).  All 18 weight stages [32 co][64 ci] sit in
-// LDS at once (T + stage buffers = 96 KB free); wave w owns positions 32w .. 32w+31. -------------------
+struct HeadRegs { float w1[32], w2[32], pv; };
+
+// every global read of the heads, issued BEFORE the last conv layer so its latency hides under that layer's MFMAs
+__device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadRegs &hr) {
+    const int grp = tid >> 7, k = tid & 127;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hr.w1[i] = hd.p1_wt[(32 * grp + i) * 128 + k];
+    const int k2 = k < MZ_ACTIONS ? k : 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) hr.w2[i] = hd.p2_wt[(32 * grp + i) * MZ_ACTIONS + k2];
+    float pv = 0.0f;   // one small parameter per thread
+    if (tid < 16) pv = hd.pc_w[tid];
+    else if (tid < 18) pv = hd.pc_b[tid - 16];
+    else if (tid < 34) pv = hd.vc_w[tid - 18];
+    else if (tid < 36) pv = hd.vc_b[tid - 34];
+    else if (tid >= 40 && tid < 168) pv = hd.p1_b[tid - 40];
+    else if (tid >= 168 && tid < 168 + MZ_ACTIONS) pv = hd.p2_b[tid - 168];
+    else if (tid >= 240 && tid < 368) pv = hd.v1_w[tid - 240];
+    else if (tid == 368) pv = hd.v1_b[0];
+    hr.pv = pv;
+}
+
+// ---- last layer: X -> hidden (global, NCHW, 8 planes) on v_mfma_f32_16x16x32_bf16: the 8 output planes are padded
+// to ONE 16-row tile (a 32x32 tile would waste 3/4 of the MFMA).  All 36 weight stages [16 co][32 ci] (36 KB, same
+// 64-byte-row swizzle as the mid layers) sit in the T region at once; wave w owns positions 32w .. 32w+31 = two
+// 16-position tiles.  D: lane -> position (l & 15), rows co = 4 (l >> 4) + 0..3, i.e. lanes 0..31 hold the 8 real planes.
 template <int OUT_DT>
-__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid,
-                                           uint32_t vm, float (&hv)[4]) {
-    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Heads &hd, HeadRegs &hr, void *__restrict__ hidden,
+                                           int64_t board0, int64_t n_boards, int tid, float (&hv)[2][4]) {
+    const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4;
     char *wl = lds + OFF_T;
-    for (int i = tid; i < LAST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wl + i * 16) = tw.w_last[i];
-    __syncthreads();
-    f32x16 acc;
+    // vmcnt retires in order: this layer's weights are requested FIRST, the heads' 65 reads behind them, so storing the
+    // weights to LDS waits only for the weights and the heads' reads stay in flight under the MFMAs below (raw barrier:
+    // __syncthreads() would drain them)
+    uint4 wreg[5];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
-    const int jt = w & 1, wkey = (r >> 1) & 7;
+    for (int i = 0; i < 5; ++i) wreg[i] = (i * 512 + tid) < LAST_W_BYTES / 16 ? tw.w_last[i * 512 + tid] : make_uint4(0, 0, 0, 0);
+    if (hd.policy) heads_prefetch(hd, tid, hr);
 #pragma unroll
-    for (int s = 0; s < LAST_STAGES; ++s) {
-        const int tap = s >> 1, kc = s & 1;
-        const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
-        const int q2 = (32 * w + r + dq) & 255;
-        const int arow = ((vm >> (tap * 2 + jt)) & 1u) ? OFF_X + q2 * 256 : OFF_Z, akey = act_key(q2);
+    for (int i = 0; i < 5; ++i)
+        if ((i * 512 + tid) < LAST_W_BYTES / 16) *reinterpret_cast<uint4 *>(wl + (i * 512 + tid) * 16) = wreg[i];
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    acc16_t acc[2] = {acc16_t{0.0f, 0.0f, 0.0f, 0.0f}, acc16_t{0.0f, 0.0f, 0.0f, 0.0f}};
+    const int waddr = c16 * 64 + ((kc ^ ((0x78 >> (((c16 >> 2) & 3) * 2)) & 3)) << 4);
+    const int x = lane & 7, y0 = (lane >> 3) & 1, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
+    // one tap = 4 k-steps = 12 fragments; the next tap's fragments are read (fenced) before this tap's 8 MFMAs issue
+    struct TapFrags { bf16x8 a[4], b[4][2]; };
+    auto load_tap = [&](int tap, TapFrags &f) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int dq = (ky - 1) * 8 + (kx - 1);
+        int arow[2], ak4[2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 a = lds_frag(wl + s * 4096 + r * 128 + (((kk * 2 + h) ^ wkey) << 4));
-            const bf16x8 b = lds_frag(lds + arow + (((kc * 8 + kk * 2 + h) ^ akey) << 4));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const int q2 = (32 * w + 16 * j + c16 + dq) & 255;
+            const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(yb + 2 * j + y0 + ky - 1) < 8u;
+            arow[j] = ok ? OFF_X + q2 * 256 : OFF_Z;
+            ak4[j] = (kc ^ act_key(q2)) << 4;
         }
-    }
-    // rows co = (reg & 3) + 8 (reg >> 2) + 4 h: the 8 real planes are registers 0..3 of both lane halves
-    const int64_t b = board0 + (w >> 1);
-    const int cell = 32 * (w & 1) + r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int co = 4 * h + k;
-        const float v = fmaxf(acc[k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
-        const uint32_t vb = bf16_rne(v);
-        hv[k] = OUT_DT == MZ_F32 ? v : bf16_up(vb);  // what the heads see = what is stored
-        if (b < n_boards) {
-            const int64_t o = b * 512 + co * 64 + cell;
-            if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = v;
-            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)vb;
+        for (int kq = 0; kq < 4; ++kq) {
+            f.a[kq] = lds_frag(wl + (tap * 4 + kq) * 1024 + waddr);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) f.b[kq][j] = lds_frag(lds + arow[j] + ((kq * 64) ^ ak4[j]));
+        }
+    };
+    TapFrags tf[2];
+    load_tap(0, tf[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) load_tap(tap + 1, tf[(tap + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const TapFrags &c = tf[tap & 1];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.a[kq], c.b[kq][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int64_t b = board0 + (w >> 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cell = 32 * (w & 1) + 16 * j + c16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = (4 * kc + k) & 7;   // lanes 32..63 hold the padding rows: computed, never stored
+            const float v = fmaxf(acc[j][k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
+            const uint32_t vb = bf16_rne(v);
+            hv[j][k] = OUT_DT == MZ_F32 ? v : bf16_up(vb);  // what the heads see = what is stored
+            if (b < n_boards && kc < 2) {
+                const int64_t o = b * 512 + co * 64 + cell;
+                if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = v;
+                else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)vb;
+            }
         }
     }
 }
@@ -429,33 +482,25 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, void *__r
 // convolutions run), and the partial sums meet in LDS.
 // LDS (the X image is dead by now), floats: hid [4][8][64] | fp [4][128] | fv [4][128] | h1 [4][128] |
 // part [4 groups][4 boards][128] | vsum [4]
-__device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const float (&hv)[4], int64_t board0, int64_t n_boards, int tid) {
+__device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const HeadRegs &hr, const float (&hv)[2][4], int64_t board0,
+                                           int64_t n_boards, int tid) {
     float *hid = reinterpret_cast<float *>(lds + OFF_X);
     float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *part = h1 + 4 * 128, *vsum = part + 4 * 4 * 128;
     float *prm = vsum + 4;   // small parameters: pc_w 16 | pc_b 2 | vc_w 16 | vc_b 2 (pad to 40) | p1_b 128 | p2_b 65 (pad 72) | v1_w 128 | v1_b 1
     float *s_pc_w = prm, *s_pc_b = prm + 16, *s_vc_w = prm + 18, *s_vc_b = prm + 34, *s_p1_b = prm + 40, *s_p2_b = prm + 168, *s_v1_w = prm + 240,
           *s_v1_b = prm + 368;
-    const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = tid >> 6, lane = tid & 63;
     const int grp = tid >> 7, k = tid & 127;   // input group / board (wave-uniform), output column
-    float w1[32], w2[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) w1[i] = hd.p1_wt[(32 * grp + i) * 128 + k];
-    const int k2 = k < MZ_ACTIONS ? k : 0;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) w2[i] = hd.p2_wt[(32 * grp + i) * MZ_ACTIONS + k2];
-    float pv = 0.0f;   // one small parameter per thread, same request batch as the matrices above (one exposed L2 latency)
-    if (tid < 16) pv = hd.pc_w[tid];
-    else if (tid < 18) pv = hd.pc_b[tid - 16];
-    else if (tid < 34) pv = hd.vc_w[tid - 18];
-    else if (tid < 36) pv = hd.vc_b[tid - 34];
-    else if (tid >= 40 && tid < 168) pv = hd.p1_b[tid - 40];
-    else if (tid >= 168 && tid < 168 + MZ_ACTIONS) pv = hd.p2_b[tid - 168];
-    else if (tid >= 240 && tid < 368) pv = hd.v1_w[tid - 240];
-    else if (tid == 368) pv = hd.v1_b[0];
+    const float(&w1)[32] = hr.w1;
+    const float(&w2)[32] = hr.w2;
     __syncthreads();  // every wave is done reading X
-    prm[tid] = pv;
+    prm[tid] = hr.pv;
+    if (lane < 32) {   // layer_last's D layout: lane -> position (lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * h + q) * 64 + 32 * (w & 1) + r] = hv[q];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + (lane & 15)] = hv[j][q];
+    }
     __syncthreads();
     {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); here grp = board
         const int c2 = k >> 6, pos = k & 63;
@@ -548,10 +593,11 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
         layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
-    float hv[4];
-    layer_last<OUT_DT>(lds, tw, hidden, board0, n_boards, tid, vm, hv);
+    float hv[2][4];
+    HeadRegs hr;
+    layer_last<OUT_DT>(lds, tw, hd, hr, hidden, board0, n_boards, tid, hv);
     MZ_STAMP(tw, 15);
-    if (hd.policy) heads_tile(lds, hd, hv, board0, n_boards, tid);
+    if (hd.policy) heads_tile(lds, hd, hr, hv, board0, n_boards, tid);
     MZ_STAMP(tw, 16);
     if (tw.stamps && threadIdx.x == 0) tw.stamps[(int64_t)blockIdx.x * 24 + 18] = (long long)__builtin_amdgcn_s_memrealtime();
 }

@@ -166,7 +166,7 @@ def pack_tower(first, blocks, last, device, cin):
             bmid.append(conv.bias.detach().float().cpu())
     return dict(w_first=wf.to(bf).to(device).contiguous(), b_first=None if first.bias is None else f32(first.bias, 128),
                 w_mid=torch.cat([torch.stack(mids).reshape(-1), torch.zeros(4 * 128 * 32)]).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),
-                w_last=_pack_stages(last.weight.detach().float().cpu(), 32, 64, 1).to(bf).to(device).contiguous(),
+                w_last=_pack_stages(last.weight.detach().float().cpu(), 16, 32, 2, (0, 2, 3, 1)).to(bf).to(device).contiguous(),
                 b_last=None if last.bias is None else f32(last.bias, 8), cin=int(cin))
 
 
