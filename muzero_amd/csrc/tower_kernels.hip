@@ -297,7 +297,9 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
             *reinterpret_cast<uint2 *>(p) = o;
         }
     }
-    __syncthreads();
+    // raw barrier (LDS only): the two weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 and are
+    // retired by its first counted waits; __syncthreads() would stall every layer boundary on them
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // ---- first layer: input planes (global, NCHW) -> X.  Uses the T region as scratch: [256 pos][16 ch]
