@@ -166,6 +166,48 @@ def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest):
     assert depth.max() >= 3
 
 
+def test_config4_size_properties_and_sampled_parity():
+    """BASELINE config 4 per-GPU size (8192 trees x 100 sims, bf16-sized pool excluded: fp32 HashNet): every tree keeps
+    the search invariants (100 visits below the root, 101 expanded nodes, no pool error, root N = 100) and a sample of
+    512 trees equals the C oracle bit for bit."""
+    from muzero_amd import env as menv
+    from muzero_amd.mcts import BatchedMCTS
+    n, S = 8192, 100
+    e = menv.BatchedEnv(n)
+    hw = torch.zeros((61, n), dtype=torch.int64, device="cuda"); hb = torch.zeros_like(hw)
+    hw[0], hb[0] = e.white, e.black
+    act = torch.empty(n, dtype=torch.uint8, device="cuda")
+    lens = torch.arange(n, device="cuda") % 60
+    for t in range(59):   # game g is advanced g mod 60 moves (255 = illegal action: state untouched)
+        e.random_action(4242, 0, t, out=act)
+        e.step(torch.where(lens > t, act, torch.full_like(act, 255)))
+        hw[t + 1], hb[t + 1] = e.white, e.black
+    img = menv.make_image(hw, hb, lens.to(torch.int32), n)
+    net = HashNetTorch("hash")
+    v0, p0, h0 = net.initial_inference(img)
+    m = BatchedMCTS(n, S)
+    m.root_init(e.to_play, e.legal, p0.contiguous(), h0.contiguous(), None)
+    m.select()
+    for s in range(S):
+        v, p, h = net.recurrent_inference(m.hidden_in, m.action_in)
+        (m.backup_select if s + 1 < S else m.expand_backup)(v.reshape(n).contiguous(), p.contiguous(), h.contiguous())
+    visits, root_value, wsum, prior = m.root_stats(with_debug=True)
+    meta = m.meta()
+    assert int(meta[:, MC.META_ERROR].max()) == 0
+    assert bool((visits.clamp(min=0).sum(1) == S).all()) and bool((meta[:, MC.META_N_NODES] == S + 1).all())
+    assert bool((meta[:, MC.META_ROOT_N] == S).all()) and bool((root_value.abs() <= 1).all())
+    legal_bits = ((e.legal.unsqueeze(1) >> torch.arange(64, device="cuda")) & 1).bool()
+    assert bool(((visits[:, :64] >= 0) == legal_bits).all()) and bool(((visits[:, 64] >= 0) == (e.legal == 0)).all())
+    visits, root_value, wsum = visits.cpu().numpy(), root_value.cpu().numpy(), wsum.cpu().numpy()
+    imgs, legal, to_play = img.cpu().numpy(), e.legal.cpu().numpy().view(np.uint64), e.to_play.cpu().numpy()
+    for g in range(0, n, 16):
+        t = O.Tree(S)
+        t.search_hashnet(to_play[g], legal[g], int(legal[g] == 0), None, R.hashnet_image_hash(imgs[g]), 0, S)
+        ov, ow, _, _, orv = t.root_stats()
+        assert (visits[g] == ov).all() and wsum[g].view(np.uint32).tolist() == ow.view(np.uint32).tolist(), g
+        assert root_value[g].view(np.uint32) == np.float32(orv).view(np.uint32), g
+
+
 def test_select_action_vs_oracle():
     from muzero_amd.mcts import select_action
     rng = np.random.default_rng(11)
