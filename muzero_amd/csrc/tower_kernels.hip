@@ -80,6 +80,12 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {  // finite inputs (post-
 __device__ __forceinline__ float bf16_up(uint32_t v) { return __uint_as_float(v << 16); }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// ReLU of two packed bf16: as signed 16-bit integers negative floats (and -0) are negative, positive floats unchanged
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    const i16x2 x = __builtin_bit_cast(i16x2, v), z = {0, 0};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, z));
+}
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even
     const f32x2 v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -152,19 +158,17 @@ struct Frags16 { bf16x8 a[4], b[4]; };
 typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
 template <bool RES>
-__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, const float *__restrict__ bias,
-                                          int tid, uint32_t vm, const Tower &tw, int stamp_id) {
+__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, f32x4 (&bv)[4],
+                                          const float *__restrict__ bias_next, int tid, uint32_t vm, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4;
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
-    // the lane's 16 bias values, requested now and first touched in the epilogue (the barrier asm below pins the loads here)
-    f32x4 bv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(bias + cobase + 16 * i + 4 * kc);
+    // the accumulators START at the bias (bv: the lane's 16 values, channels cobase + 16 i + 4 kc + 0..3, requested during
+    // the previous layer's epilogue), so the epilogue has no bias add
     acc16_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = acc16_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
 
     char *wring = lds + OFF_W;
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
@@ -268,6 +272,11 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     }
 
     MZ_STAMP(tw, stamp_id);
+    // the next layer's bias: two thousand cycles of epilogue ahead of its first use
+    if (bias_next) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(bias_next + cobase + 16 * i + 4 * kc);
+    }
     // epilogue: lane = position, the 4 registers of a tile = channels co0 .. co0 + 3
     char *dst = lds + dst_off;
 #pragma unroll
@@ -281,7 +290,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
             char *p = row + ((chunk ^ key) << 4);
             float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k] + bv[i][k];
+            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
             if (RES) {
                 const uint2 xr = *reinterpret_cast<const uint2 *>(p);
                 v[0] += bf16_up(xr.x & 0xFFFFu);
@@ -289,11 +298,9 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
                 v[2] += bf16_up(xr.y & 0xFFFFu);
                 v[3] += bf16_up(xr.y >> 16);
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.0f);
-            uint2 o;
-            o.x = pack_bf16(v[0], v[1]);
-            o.y = pack_bf16(v[2], v[3]);
+            uint2 o;   // round, then ReLU on the packed bf16 pair (same result as ReLU then round: rounding keeps the sign)
+            o.x = relu_bf16x2(pack_bf16(v[0], v[1]));
+            o.y = relu_bf16x2(pack_bf16(v[2], v[3]));
             *reinterpret_cast<uint2 *>(p) = o;
         }
     }
@@ -583,6 +590,9 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     MZ_STAMP(tw, 0);
     if (tw.stamps && threadIdx.x == 0) tw.stamps[(int64_t)blockIdx.x * 24 + 17] = (long long)__builtin_amdgcn_s_memrealtime();
     mid_prologue(lds, tw.w_mid, tid);
+    f32x4 bv[4];   // bias of the first mid layer in the K loop's accumulator layout (see layer_mid)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(tw.b_mid + 64 * ((tid >> 6) & 1) + 16 * i + 4 * ((tid & 63) >> 4));
     layer_first(lds, tw, x, board0, n_boards, tid, vm);
     MZ_STAMP(tw, 1);
     MZ_STAMP(tw, 2);
@@ -590,9 +600,9 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     for (int blk = 0; blk < 3; ++blk) {
         const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 512;
         const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 512;
-        layer_mid<false>(lds, OFF_X, OFF_T, w0, tw.b_mid + (2 * blk) * 128, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
+        layer_mid<false>(lds, OFF_X, OFF_T, w0, bv, tw.b_mid + (2 * blk + 1) * 128, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
         MZ_STAMP(tw, 4 + 4 * blk);
-        layer_mid<true>(lds, OFF_T, OFF_X, w1, tw.b_mid + (2 * blk + 1) * 128, tid, vm, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
+        layer_mid<true>(lds, OFF_T, OFF_X, w1, bv, blk < 2 ? tw.b_mid + (2 * blk + 2) * 128 : nullptr, tid, vm, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
     float hv[2][4];
