@@ -348,13 +348,171 @@ __global__ void __launch_bounds__(64) k_expand_backup(Pool P, mz_search_cfg cfg,
                                                       const char *hidden) {
     tree_expand_backup(P, cfg, value, policy, hidden, blockIdx.x, threadIdx.x);
 }
+// ---- the fused simulation step, latency-optimised ------------------------------------------------
+// expand_node + backpropagate of simulation s and the descent of simulation s+1 for one tree, as the
+// three device functions above compute them -- same arithmetic, same stores -- but organised around
+// the one thing that bounds this kernel: the chain of DEPENDENT cold loads (each ~1-2 us from HBM).
+//   round 0  everything whose address is known at launch is requested together: meta, the old path,
+//            policy row, value, the new hidden state, and the ROOT's 65 child records
+//   round 1  the backup's records (addresses from the old path) and the root's pb_c entry
+//   then     the descent runs on registers: records this step has just modified are never re-read
+//            from memory -- the root's and every node's on the old path are patched in registers
+//            with the backup lane's new (N, W), the freshly expanded node's records are rebuilt from
+//            the priors it was given, and its hidden state goes to the network input straight from
+//            the registers that copied it in.  Only nodes off the old path cost a round each.
+// Typical step (old depth 1-2, new depth 1-2): 3-4 rounds instead of 8-9.  Paths longer than 62
+// edges (degenerate chains) take the plain three-function route.
 __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg, const float *value, const float *policy,
                                                       const char *hidden, char *net_in) {
-    tree_expand_backup(P, cfg, value, policy, hidden, blockIdx.x, threadIdx.x);
-    // the descent re-reads records other lanes of this wave have just written: make them visible
-    // within the workgroup (one wave) before reading
-    __syncthreads();
-    tree_select(P, cfg, net_in, blockIdx.x, threadIdx.x);
+    const int t = blockIdx.x, lane = threadIdx.x;
+    mz_tree_meta *meta = &P.meta[t];
+    const int depth = meta->path_len;
+    if (depth > 62) {
+        tree_expand_backup(P, cfg, value, policy, hidden, t, lane);
+        __syncthreads();  // the descent re-reads records other lanes of this wave have just written
+        tree_select(P, cfg, net_in, t, lane);
+        return;
+    }
+    const int64_t tbase = (int64_t)t * P.max_nodes;
+    const int eb = P.hidden_elem_bytes, n16 = (MZ_HIDDEN_ELEMS * eb) >> 4;  // 128 (f32) or 64 (16-bit) uint4 per hidden state
+    // ---- round 0 ----
+    const int new_id = meta->n_nodes;
+    int root_n = meta->root_n;
+    float root_w = meta->root_w;
+    const int root_player = meta->root_player;
+    MinMax mm = load_minmax(meta);
+    int mm_flags = meta->mm_flags;
+    const PathRec oldp = lane < P.max_nodes ? P.path[tbase + lane] : PathRec{0, 0, 0};  // old search_path edge `lane`
+    const float pol = policy[(int64_t)t * MZ_ACTIONS + lane], pol64 = policy[(int64_t)t * MZ_ACTIONS + 64];
+    const float v0 = value[t];
+    const uint4 *hsrc = reinterpret_cast<const uint4 *>(hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb));
+    const uint4 hin0 = hsrc[lane];
+    const uint4 hin1 = n16 > 64 ? hsrc[lane + 64] : make_uint4(0, 0, 0, 0);
+    const ChildRec *root_recs = P.stats + tbase * MZ_ACTIONS;
+    ChildRec r = root_recs[lane], r64 = root_recs[64];
+
+    const bool ok = new_id < P.max_nodes && depth >= 1;   // tree_expand's guard
+    double prior = 0.0, prior64 = 0.0;
+    uint32_t b_nc = 0;     // backup lane k: the new (nc, w) of search_path[k]'s record
+    float b_w = 0.0f;
+    if (ok) {
+        // ---- expand_node main.py:165-175 over all 65 actions (write_children<true>, keeping the priors) ----
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) sum += (double)lane_f32(pol, i);
+        sum += (double)pol64;
+        prior = (double)pol / sum;
+        prior64 = (double)pol64 / sum;
+        ChildRec *nrecs = P.stats + (tbase + new_id) * MZ_ACTIONS;
+        nrecs[lane] = ChildRec{0u, 0.0f, prior};
+        if (lane == 0) nrecs[64] = ChildRec{0u, 0.0f, prior64};
+        uint4 *hdst = reinterpret_cast<uint4 *>(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb));
+        hdst[lane] = hin0;
+        if (n16 > 64) hdst[lane + 64] = hin1;
+        // ---- backpropagate main.py:180-186: lane k owns search_path[k], k = 0 .. depth ----
+        const int prev = __shfl_up(*reinterpret_cast<const int *>(&oldp), 1, 64);   // path[k-1]
+        const int pnode = prev & 0xFFFF, pact = (prev >> 16) & 0xFF;
+        const float disc = (float)cfg.discount;
+        float vmin = INFINITY, vmax = -INFINITY;
+        if (lane <= depth) {
+            float v = v0;
+            for (int i = 0; i < lane; ++i) v = 0.0f + disc * v;  // node.reward (0) + discount * value
+            const float sv = ((depth - lane) & 1) ? -v : v;
+            float nv;
+            if (lane == 0) {
+                root_w = root_w + sv;
+                root_n = root_n + 1;
+                nv = root_w / (float)root_n;
+            } else {
+                ChildRec *rec = P.stats + (tbase + pnode) * MZ_ACTIONS + pact;
+                uint32_t nc = rec->nc;   // ---- round 1 ----
+                const float w = rec->w + sv;
+                if (lane == depth) nc = (nc & 0xFFFFu) | ((uint32_t)(new_id + 1) << 16);  // tree_expand's link of the leaf to its node
+                nc += 1u;
+                rec->nc = nc;
+                rec->w = w;
+                b_nc = nc;
+                b_w = w;
+                nv = w / (float)(nc & 0xFFFFu);
+            }
+            vmin = nv;
+            vmax = nv;
+        }
+        root_n = __shfl(root_n, 0, 64);
+        root_w = __shfl(root_w, 0, 64);
+        vmin = wave_min_f32(vmin);
+        vmax = wave_max_f32(vmax);
+        // MinMaxStats.update (utilities.py:121-123), as tree_backup
+        if (mx_lt(mx_t(vmin), mm.lo)) { mm.lo = mx_t(vmin); mm_flags |= 1; }
+        if (mx_gt(mx_t(vmax), mm.hi)) { mm.hi = mx_t(vmax); mm_flags |= 2; }
+    }
+
+    // ---- descent of the next simulation (tree_select) on registers ----
+    const bool tie_lowest = cfg.tie_lowest != 0;
+    int node = 0, level = 0, a = 0, player = root_player;
+    uint32_t np = (uint32_t)root_n;
+    for (;;) {
+        if (ok && level < depth && (int)(__shfl(*reinterpret_cast<const int *>(&oldp), level, 64) & 0xFFFF) == node) {
+            // this node's record for the old path's action was rewritten by backup lane level + 1: take it from there
+            const int pa = (__shfl(*reinterpret_cast<const int *>(&oldp), level, 64) >> 16) & 0xFF;
+            const uint32_t pnc = (uint32_t)__shfl((int)b_nc, level + 1, 64);
+            const float pw = __shfl(b_w, level + 1, 64);
+            if (pa == 64) { r64.nc = pnc; r64.w = pw; }
+            else if (lane == pa) { r.nc = pnc; r.w = pw; }
+        }
+        const PbcRec pb = P.pbc[np];
+        const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+        a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
+        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
+        if (lane == 0) P.path[tbase + level] = PathRec{(uint16_t)node, (uint8_t)a, 0};
+        ++level;
+        player = -player;
+        const uint32_t child = nc >> 16;
+        if (child == 0 || level >= P.max_nodes) break;
+        node = (int)child - 1;
+        np = nc & 0xFFFFu;
+        if (ok && node == new_id) {   // the node expanded a moment ago: its records are the priors it was given
+            r = ChildRec{0u, 0.0f, prior};
+            r64 = ChildRec{0u, 0.0f, prior64};
+        } else {
+            const ChildRec *recs = P.stats + (tbase + node) * MZ_ACTIONS;
+            r = recs[lane];
+            r64 = recs[64];
+        }
+    }
+    if (lane == 0) {
+        if (ok) {
+            meta->n_nodes = new_id + 1;
+            meta->root_w = root_w;
+            meta->root_n = root_n;
+            meta->mm_min = mm.lo.d;
+            meta->mm_max = mm.hi.d;
+            meta->mm_flags = mm_flags;
+        } else {
+            meta->error |= 1;
+        }
+        meta->path_len = level;
+        meta->leaf_player = player;
+        meta->leaf_parent = node;
+        meta->leaf_action = a;
+    }
+    // network input row: parent hidden (8 planes) ++ Action(a, child's player).encode() (2 planes)
+    char *row = net_in + (int64_t)t * (640 * eb);
+    uint4 *rdst = reinterpret_cast<uint4 *>(row);
+    if (ok && node == new_id) {
+        rdst[lane] = hin0;
+        if (n16 > 64) rdst[lane + 64] = hin1;
+    } else {
+        const uint4 *ps = reinterpret_cast<const uint4 *>(P.hidden + (tbase + node) * (int64_t)(MZ_HIDDEN_ELEMS * eb));
+        rdst[lane] = ps[lane];
+        if (n16 > 64) rdst[lane + 64] = ps[lane + 64];
+    }
+    const int layer = lane >> 5, cell = (2 * lane) & 63, my_layer = player == 1 ? 0 : 1;
+    const bool set = layer == my_layer && ((encode_rows(a) >> (cell >> 3)) & 1u);
+    if (eb == 4)
+        ((float2 *)(row + 512 * 4))[lane] = set ? make_float2(1.0f, 1.0f) : make_float2(0.0f, 0.0f);
+    else
+        ((uint32_t *)(row + 512 * 2))[lane] = set ? P.one16x2 : 0u;
 }
 
 // ---- single-call entry points for the reference-shaped Python API (muzero_amd/compat.py) ----------
