@@ -123,30 +123,21 @@ class Network(nn.Module):
         return self.steps
 
 
-def _swizzle_rows(w, shift, perm=None):
-    """(rows, C ci) -> (rows, C/8 slots, 8): 16-byte chunk c of row `co` goes to slot c ^ key(co), key = (co >> shift) &
-    (C/8 - 1), optionally mapped through `perm` -- the LDS image tower_kernels.hip reads conflict-free (XOR is an
-    involution, so slot s holds chunk s ^ key)"""
-    rows, nch = w.shape[0], w.shape[1] // 8
-    ch = w.reshape(rows, nch, 8)
-    key = (torch.arange(rows, device=w.device) >> shift) & (nch - 1)
-    if perm is not None:
-        key = torch.tensor(perm, device=w.device)[key]
-    idx = torch.arange(nch, device=w.device).unsqueeze(0) ^ key.unsqueeze(1)      # (rows, nch): chunk held by each slot
-    return torch.gather(ch, 1, idx.unsqueeze(-1).expand(rows, nch, 8))
+_PERM = (0, 2, 3, 1)   # weight chunk swizzle key of tower_kernels.hip: slot = chunk ^ _PERM[(co >> 2) & 3]
 
 
-def _pack_stages(w, rows, cchunk, shift, perm=None):
-    """conv weight (co, 128, 3, 3) -> (9 * 128/cchunk stages, rows, cchunk/8, 8): stage = (ky*3+kx) * (128/cchunk) + ci/cchunk,
-    co zero-padded to rows"""
-    co = w.shape[0]
-    out = []
-    for tap in range(9):
-        for kc in range(128 // cchunk):
-            blk = torch.zeros((rows, cchunk), dtype=w.dtype, device=w.device)
-            blk[:co] = w[:, kc * cchunk:(kc + 1) * cchunk, tap // 3, tap % 3]
-            out.append(_swizzle_rows(blk, shift, perm))
-    return torch.stack(out)
+def _pack_stages(w, rows):
+    """conv weight (co, 128, 3, 3) -> (36 stages, rows, 4 slots, 8) on w's device: stage = (ky*3+kx)*4 + ci/32, co
+    zero-padded to `rows`; the 16-byte chunk c of a row's 32 input channels sits in slot c ^ _PERM[(co >> 2) & 3] -- the
+    LDS image tower_kernels.hip reads conflict-free (XOR is an involution, so slot s holds chunk s ^ key).  A handful of
+    device ops, no host round trip: publishing new weights costs well under a millisecond."""
+    co, dev = w.shape[0], w.device
+    full = torch.zeros((rows, 128, 3, 3), dtype=w.dtype, device=dev)
+    full[:co] = w
+    st = full.permute(2, 3, 1, 0).reshape(9, 4, 32, rows).permute(0, 1, 3, 2).reshape(36, rows, 4, 8)   # (stage, co, chunk, 8)
+    key = torch.tensor(_PERM, device=dev)[(torch.arange(rows, device=dev) >> 2) & 3]
+    idx = torch.arange(4, device=dev).unsqueeze(0) ^ key.unsqueeze(1)                                    # (rows, 4): chunk held by each slot
+    return torch.gather(st, 2, idx.view(1, rows, 4, 1).expand(36, rows, 4, 8))
 
 
 def pack_tower(first, blocks, last, device, cin):
@@ -154,20 +145,17 @@ def pack_tower(first, blocks, last, device, cin):
     bf16 LDS images mz_tower_forward streams (include/muzero_amd.h mz_tower_weights).  Returns a dict of device
     tensors (kept alive by the caller) holding the layout documented there."""
     bf = torch.bfloat16
-    f32 = lambda b, n: (torch.zeros(n) if b is None else b.detach().float()).to(device).contiguous()  # noqa: E731
-    wf = torch.zeros((9, 128, 16), dtype=torch.float32)
-    w1 = first.weight.detach().float().cpu()
-    for tap in range(9):
-        wf[tap, :, :cin] = w1[:, :, tap // 3, tap % 3]
-    mids, bmid = [], []
-    for blk in blocks:
-        for conv in (blk.block[0], blk.block[2]):
-            mids.append(_pack_stages(conv.weight.detach().float().cpu(), 128, 32, 2, (0, 2, 3, 1)))
-            bmid.append(conv.bias.detach().float().cpu())
-    return dict(w_first=wf.to(bf).to(device).contiguous(), b_first=None if first.bias is None else f32(first.bias, 128),
-                w_mid=torch.cat([torch.stack(mids).reshape(-1), torch.zeros(4 * 128 * 32)]).to(bf).to(device).contiguous(), b_mid=torch.stack(bmid).to(device).contiguous(),
-                w_last=_pack_stages(last.weight.detach().float().cpu(), 16, 32, 2, (0, 2, 3, 1)).to(bf).to(device).contiguous(),
-                b_last=None if last.bias is None else f32(last.bias, 8), cin=int(cin))
+    dev = torch.device(device)
+    f = lambda t: t.detach().to(dev).float()  # noqa: E731
+    wf = torch.zeros((9, 128, 16), dtype=torch.float32, device=dev)
+    wf[:, :, :cin] = f(first.weight).permute(2, 3, 0, 1).reshape(9, 128, cin)
+    convs = [c for blk in blocks for c in (blk.block[0], blk.block[2])]
+    w_mid = torch.cat([torch.stack([_pack_stages(f(c.weight), 128) for c in convs]).reshape(-1),
+                       torch.zeros(4 * 128 * 32, device=dev)])   # + 4 stages of padding: the stream prefetches past the end
+    return dict(w_first=wf.to(bf).contiguous(), b_first=None if first.bias is None else f(first.bias).contiguous(),
+                w_mid=w_mid.to(bf).contiguous(), b_mid=torch.stack([f(c.bias) for c in convs]).contiguous(),
+                w_last=_pack_stages(f(last.weight), 16).to(bf).contiguous(),
+                b_last=None if last.bias is None else f(last.bias).contiguous(), cin=int(cin))
 
 
 class InferenceEngine:
