@@ -176,9 +176,18 @@ def bench_train(args, device, rec):
         p_loss, v_loss = T.update_weights(opt, net, rb.sample_batch(K), bucket)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    t0 = time.perf_counter()
+    for _ in range(3 + iters):
+        if _ == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        T.update_weights(opt, net, rb.sample_batch(K), bucket, amp_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    dt_amp = (time.perf_counter() - t0) / iters
     config.num_unroll_steps = 3
     return {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
-            "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss)}
+            "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss),
+            "bf16_autocast_ms_per_step": dt_amp * 1e3}
 
 
 def bench_cpu_baseline(args):

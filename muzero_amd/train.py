@@ -90,14 +90,22 @@ def muzero_loss(network, batch):
     return p_loss, v_loss
 
 
-def update_weights(optimizer, network, batch, bucket=None, group=None):
+def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None):
     """main.py:230-272.  With `bucket` (FlatGradBucket over network.parameters()) the gradients are
-    averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step."""
+    averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step.
+    amp_dtype (e.g. torch.bfloat16): run the forward/backward convolutions under torch.autocast (fp32 master
+    weights, gradients and optimiser state stay fp32); None = the reference's fp32 arithmetic."""
     if bucket is not None:
         bucket.zero()
     else:
         optimizer.zero_grad()
-    p_loss, v_loss = muzero_loss(network, batch)
+    if amp_dtype is not None:
+        dev = next(network.parameters()).device
+        with torch.autocast(dev.type, dtype=amp_dtype):
+            p_loss, v_loss = muzero_loss(network, batch)
+        p_loss, v_loss = p_loss.float(), v_loss.float()
+    else:
+        p_loss, v_loss = muzero_loss(network, batch)
     (p_loss + v_loss).backward()
     if bucket is not None:
         bucket.all_reduce_mean(group)
