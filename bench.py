@@ -156,6 +156,7 @@ def bench_train(args, device, rec):
     from muzero_amd.replay import ReplayBuffer
     B, K = args.train_batch, args.train_unroll
     config.num_unroll_steps = K
+    T.LOG = None   # stdout carries the one JSON line only
     rb = ReplayBuffer(device, window_size=max(rec.n, B), batch_size=B)
     while rb.buffer_size < B:
         rb.save_games(rec)

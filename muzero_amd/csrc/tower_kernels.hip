@@ -7,27 +7,29 @@
 // (value, policy, hidden) tuple of initial_inference / recurrent_inference (network.py:146-163).
 //
 // Why one kernel.  An 8x8 board with 128 channels is 16 KB in bf16, so FOUR boards (256 positions,
-// the GEMM M dimension) and both activation tensors a residual block needs fit in the 160 KB LDS of
+// the GEMM N dimension) and both activation tensors a residual block needs fit in the 160 KB LDS of
 // one CU.  A workgroup therefore carries its four boards through all eight layers without ever
 // writing an activation to HBM: per tile it reads 5 KB of input planes, writes 4 KB of hidden
 // state, and streams the layer weights (295 KB per 128->128 layer, L2-resident: every workgroup
-// reads the same 1.9 MB) through a double-buffered 2 x 16 KB LDS stage.  HBM traffic drops from
-// ~200 MB per layer to ~10 MB per tower; what is left is MFMA work.
+// reads the same 1.9 MB) through a ring of four 8 KB LDS buffers.  HBM traffic drops from
+// ~200 MB per layer to ~27 MB per launch; what is left is MFMA work.
 //
-// Mapping (one workgroup = 512 threads = 8 waves, 2 per SIMD; static LDS = 163,840 B):
+// Mapping (one workgroup = 512 threads = 8 waves, 2 per SIMD; static LDS = 163,840 B = X image 64 KB |
+// T image 64 KB | weight ring 4 x 8 KB):
 //   GEMM per layer: D[co][pos] = sum_{tap,ci} W[tap][co][ci] * X[pos + shift(tap)][ci]
-//   MFMA v_mfma_f32_32x32x16_bf16 with A = weights (rows = co), B = activations (cols = pos), so a
-//   lane ends up holding ONE position and 4-element runs of consecutive channels: the epilogue
-//   (bias, residual, ReLU, bf16 rounding) writes 8-byte pieces straight back into the [pos][ch] LDS
-//   image the next layer reads -- no transpose, no shuffle.
-//   wave w: co half (w & 1) x board (w >> 1)  ->  2 x 2 accumulator tiles of 32 x 32 per wave.
-//   K loop: 9 taps x 4 channel quarters = 36 stages of [128 co][32 ci] through a ring of three 8 KB
-//   LDS buffers; one barrier per stage, and fragment reads run one k-step ahead ACROSS the barrier
-//   (layer_mid), so the MFMA stream never drains at a stage boundary.
+//   v_mfma_f32_16x16x32_bf16 (first layer: 32x32x16) with A = weights (rows = co), B = activations
+//   (cols = pos), so a lane ends up holding ONE position and 4-element runs of consecutive channels: the
+//   epilogue (residual, bf16 rounding, ReLU) writes 8-byte pieces straight back into the [pos][ch] LDS
+//   image the next layer reads -- no transpose, no shuffle.  The accumulators start at the bias.
+//   wave w: co half (w & 1) x board (w >> 1)  ->  a 4 x 4 grid of 16 x 16 accumulators per wave.
+//   K loop: 9 taps x 4 channel quarters = 36 stages of [128 co][32 ci], filled by LDS-DMA three stages
+//   ahead; one counted raw barrier per stage, and fragment reads run one whole stage ahead ACROSS the
+//   barrier (layer_mid), so the MFMA stream never drains at a stage boundary.
 //   The 3x3 halo needs no padding ring in the activation image: a lane whose shifted position leaves
-//   the board reads its fragment from a block of zeros instead.
+//   the board reads its fragment past the end of the LDS allocation, which returns zeros (OFF_Z).
 // LDS images are XOR-swizzled in 16-byte chunks so every ds_read_b128 lane group hits 16 distinct
-// 4-bank slots: activations  slot = chunk ^ ((y & 1) << 3 | x),  weights (64-byte rows)  slot = chunk ^ perm[(co >> 2) & 3], perm = {0, 2, 3, 1}.
+// 4-bank slots: activations  slot = chunk ^ ((y & 1) << 3 | x),  weights (64-byte rows)  slot = chunk ^ perm[(co >> 2) & 3], perm = {0, 2, 3, 1};
+// the MFMA column -> board cell map (col_cell) is chosen for the hardware's non-contiguous lane groups.
 // Weights arrive PREPACKED in exactly these images (muzero_amd/network.py: pack_tower), so staging
 // is a linear copy.
 #include "common.h"
@@ -72,6 +74,11 @@ struct Heads {
 };
 
 __device__ __forceinline__ int act_key(int q) { return (((q >> 3) & 1) << 3) | (q & 7); }
+// MFMA 16x16x32 column c (= lane & 15) -> cell of the 16-position tile (2 board rows).  ds_read_b128 is served in the lane
+// groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): columns {0-3,12-15} of one k-chunk share a
+// group with columns {4-11} of the NEXT k-chunk.  Giving {0-3,12-15} the tile's first board row and {4-11} its second
+// keeps the two sets on different values of the key's row bit for every tap shift, so a group's 16 reads hit 16 distinct slots.
+__device__ __forceinline__ int col_cell(int c) { return c < 4 ? c : (c < 12 ? c + 4 : c - 8); }
 
 __device__ __forceinline__ uint32_t bf16_rne(float f) {  // finite inputs (post-ReLU)
     const uint32_t u = __float_as_uint(f);
@@ -121,14 +128,15 @@ __device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restric
 }
 
 // ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
-// K loop: 36 stages of [128 co][32 ci] weights (8 KB; 2 k-steps of 16 channels = 8 MFMAs per wave)
-// through a ring of FOUR LDS buffers filled by LDS-DMA, software-pipelined one whole stage deep:
-//   iteration i, after barrier B_i:  write stage i+2 to the ring (from registers, fetched two
-//   iterations ago), issue the global load of stage i+4, read the 8 fragments of stage i+1 into the
-//   other fragment set, and run the 8 MFMAs of stage i on the set read during iteration i-1.
-// B_i orders "all waves finished stage i-1" (buffer (i+2)%3 = (i-1)%3 is free) and "all waves wrote
-// stage i+1" (in iteration i-1), so stage i+1 is readable anywhere in iteration i.  Nothing an MFMA
-// consumes was requested less than a stage ago, and the barrier's lgkmcnt(0) finds its reads done.
+// K loop: 36 stages of [128 co][32 ci] weights (8 KB = one K = 32 step = 16 MFMAs per wave) through a
+// ring of FOUR LDS buffers filled by LDS-DMA, software-pipelined one whole stage deep:
+//   iteration i, after barrier B_i:  run the 16 MFMAs of stage i on the fragment set read during
+//   iteration i-1, read the 8 fragments of stage i+1 into the other set (between the MFMAs), and issue
+//   the DMA of stage i+3 into the buffer stage i-1 has left.
+// B_i (s_waitcnt vmcnt(1) + s_barrier) orders "all waves finished reading stage i-1" (its buffer is
+// free) and "every wave's DMA piece of stage i+1 has landed", so stage i+1 is readable anywhere in
+// iteration i.  Nothing an MFMA consumes was requested less than a stage ago, and the barrier's
+// lgkmcnt(0) finds its reads done.
 // The weight stream is one contiguous array over all six layers (+ 4 stages of padding): it simply
 // keeps running across layer boundaries, so only the first layer pays a prologue (mid_prologue).
 // Halo: a lane whose shifted position leaves the board reads its fragment from a 256-byte block of
@@ -160,7 +168,7 @@ typedef __attribute__((ext_vector_type(4))) float acc16_t;
 template <bool RES>
 __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, f32x4 (&bv)[4],
                                           const float *__restrict__ bias_next, int tid, uint32_t vm, const Tower &tw, int stamp_id) {
-    const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4;
+    const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
     // the accumulators START at the bias (bv: the lane's 16 values, channels cobase + 16 i + 4 kc + 0..3, requested during
     // the previous layer's epilogue), so the epilogue has no bias add
@@ -180,13 +188,13 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     }
     // activations per tap: row base (or the out-of-range zero block) and (kc ^ key) << 4; tile j = board rows 2j, 2j + 1
     int arow[4], ak4[4];
-    const int x = lane & 7, y0 = (lane >> 3) & 1;
+    const int x = p16 & 7, y0 = p16 >> 3;
     auto set_tap = [&](int ky, int kx) {   // tap = 3 ky + kx
         const int dq = (ky - 1) * 8 + (kx - 1);
         const bool okx = (unsigned)(x + kx - 1) < 8u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int q2 = (posbase + 16 * j + c16 + dq) & 255;
+            const int q2 = (posbase + 16 * j + p16 + dq) & 255;
             const bool ok = okx && (unsigned)(2 * j + y0 + ky - 1) < 8u;
             arow[j] = ok ? src_off + q2 * 256 : OFF_Z;
             ak4[j] = (kc ^ act_key(q2)) << 4;
@@ -281,7 +289,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     char *dst = lds + dst_off;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int q = posbase + 16 * j + c16;
+        const int q = posbase + 16 * j + p16;
         char *row = dst + q * 256 + (kc & 1) * 8;
         const int key = act_key(q);
 #pragma unroll
@@ -416,7 +424,7 @@ __device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadReg
 template <int OUT_DT>
 __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Heads &hd, HeadRegs &hr, void *__restrict__ hidden,
                                            int64_t board0, int64_t n_boards, int tid, float (&hv)[2][4]) {
-    const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4;
+    const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     char *wl = lds + OFF_T;
     // vmcnt retires in order: this layer's weights are requested FIRST, the heads' 65 reads behind them, so storing the
     // weights to LDS waits only for the weights and the heads' reads stay in flight under the MFMAs below (raw barrier:
@@ -431,7 +439,7 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     acc16_t acc[2] = {acc16_t{0.0f, 0.0f, 0.0f, 0.0f}, acc16_t{0.0f, 0.0f, 0.0f, 0.0f}};
     const int waddr = c16 * 64 + ((kc ^ ((0x78 >> (((c16 >> 2) & 3) * 2)) & 3)) << 4);
-    const int x = lane & 7, y0 = (lane >> 3) & 1, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
+    const int x = p16 & 7, y0 = p16 >> 3, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
     // one tap = 4 k-steps = 12 fragments; the next tap's fragments are read (fenced) before this tap's 8 MFMAs issue
     struct TapFrags { bf16x8 a[4], b[4][2]; };
     auto load_tap = [&](int tap, TapFrags &f) {
@@ -440,7 +448,7 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
         int arow[2], ak4[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int q2 = (32 * w + 16 * j + c16 + dq) & 255;
+            const int q2 = (32 * w + 16 * j + p16 + dq) & 255;
             const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(yb + 2 * j + y0 + ky - 1) < 8u;
             arow[j] = ok ? OFF_X + q2 * 256 : OFF_Z;
             ak4[j] = (kc ^ act_key(q2)) << 4;
@@ -468,7 +476,7 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
     const int64_t b = board0 + (w >> 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int cell = 32 * (w & 1) + 16 * j + c16;
+        const int cell = 32 * (w & 1) + 16 * j + p16;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int co = (4 * kc + k) & 7;   // lanes 32..63 hold the padding rows: computed, never stored
@@ -504,11 +512,11 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const Hea
     const float(&w2)[32] = hr.w2;
     __syncthreads();  // every wave is done reading X
     prm[tid] = hr.pv;
-    if (lane < 32) {   // layer_last's D layout: lane -> position (lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
+    if (lane < 32) {   // layer_last's D layout: lane -> cell col_cell(lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + (lane & 15)] = hv[j][q];
+            for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + col_cell(lane & 15)] = hv[j][q];
     }
     __syncthreads();
     {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); here grp = board

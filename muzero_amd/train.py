@@ -68,6 +68,9 @@ def make_optimizer(network):
     return optim.SGD(network.parameters(), lr=0.001, weight_decay=config.lr_decay_rate, momentum=config.momentum)
 
 
+LOG = print   # progress lines as the reference prints them; set to None to silence (bench.py does: its stdout is one JSON line)
+
+
 def muzero_loss(network, batch):
     """main.py:239-265: K-step unrolled loss.  Returns (p_loss, v_loss) tensors.
     p_loss = mean over (B, K+1) of -sum_a pi log p ; v_loss = mean over B of sum_k (z - v)^2."""
@@ -112,8 +115,8 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
     elif _dist_on(group):
         raise RuntimeError("data-parallel update_weights needs a FlatGradBucket")
     optimizer.step()
-    if network.steps % 10 == 0:
-        print('step {}: p_loss {:.4f} v_loss {:.4f}'.format(network.steps, float(p_loss.detach()), float(v_loss.detach())))
+    if LOG is not None and network.steps % 10 == 0:   # main.py:268-269; the float() is a device sync
+        LOG('step {}: p_loss {:.4f} v_loss {:.4f}'.format(network.steps, float(p_loss.detach()), float(v_loss.detach())))
     network.steps += 1
     return p_loss.detach(), v_loss.detach()
 

@@ -1,0 +1,137 @@
+// mfma_rate.hip -- what does the K loop of k_tower cost on bare hardware?  Micro-benchmark, not product code.
+// One workgroup per CU (all 160 KB of LDS claimed, as k_tower does), 4 or 8 waves, each running ITER "stages" of
+// 16 independent v_mfma_f32_16x16x32_bf16 (the stage of layer_mid) with, optionally, the stage's other ingredients:
+//   R  8 conflict-free ds_read_b128 per stage, placed as in layer_mid (2 behind every second MFMA)
+//   B  the counted raw barrier per stage
+//   D  one 1-KB LDS-DMA per wave per stage
+// Prints shader cycles per stage (wave 0 of every block, averaged) next to the 16-cycle-per-MFMA ideal.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_rate.hip -o tools/mfma_rate.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int LDS_BYTES = 163840;
+constexpr int ITER = 2048;
+
+#define CK(x)                                                                        \
+    do {                                                                             \
+        hipError_t e_ = (x);                                                         \
+        if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
+    } while (0)
+
+template <bool R, bool B, bool D, int P = 0>
+__global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, float *out, long long *cyc) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int i = tid; i < LDS_BYTES / 16; i += blockDim.x) reinterpret_cast<uint4 *>(lds)[i] = src[i & 4095];
+    __syncthreads();
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[2][4], b[2][4];
+    // conflict-free: 64 lanes x 16 B contiguous, a different KB per fragment and wave
+    const char *base = lds + w * 8192 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[0][i] = a[1][i] = *reinterpret_cast<const bf16x8 *>(base + i * 1024);
+        b[0][i] = b[1][i] = *reinterpret_cast<const bf16x8 *>(base + (4 + i) * 1024);
+    }
+    __syncthreads();
+    uint4 stg = make_uint4(0, 0, 0, 0);   // P == 5: register-staged copy (global_load_dwordx4 now, ds_write_b128 one stage later)
+    const long long t0 = __builtin_readcyclecounter();
+#define MF(s, i, j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[4 * i + j], 0, 0, 0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DMA()                                                                                                                        \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((it + s) & 7) * 512 + tid),            \
+                                     (__attribute__((address_space(3))) void *)(lds + 131072 + ((it + s) & 3) * 8192 + w * 1024), 16, 0, 0)
+#define RD(dst, off) if (R) dst = *reinterpret_cast<const bf16x8 *>(base + (off) * 1024)
+#pragma unroll 1
+    for (int it = 0; it < ITER; it += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (B) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (R) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MF(s, 0, 0); MF(s, 0, 1); FENCE();
+            RD(a[s ^ 1][0], 0); RD(a[s ^ 1][1], 1); FENCE();
+            MF(s, 0, 2); MF(s, 0, 3); FENCE();
+            if (D && (P == 1 || (P == 2 && (w >> 2) == 0) || (P == 3 && (w & 1) == 0) || (P == 4 && (w >> 2) == 0))) { DMA(); FENCE(); }
+            if (D && P == 5) { *reinterpret_cast<uint4 *>(lds + 131072 + ((it + s) & 3) * 8192 + tid * 16) = stg; FENCE(); }
+            RD(b[s ^ 1][0], 4); RD(b[s ^ 1][1], 5); FENCE();
+            MF(s, 1, 0); MF(s, 1, 1); FENCE();
+            RD(a[s ^ 1][2], 2); RD(a[s ^ 1][3], 3); FENCE();
+            MF(s, 1, 2); MF(s, 1, 3); FENCE();
+            RD(b[s ^ 1][2], 6); RD(b[s ^ 1][3], 7); FENCE();
+            MF(s, 2, 0); MF(s, 2, 1); MF(s, 2, 2); MF(s, 2, 3); FENCE();
+            if (D && (P == 4 && (w >> 2) == 1)) { DMA(); FENCE(); }
+            MF(s, 3, 0); MF(s, 3, 1); MF(s, 3, 2); MF(s, 3, 3); FENCE();
+            if (D && P == 5) { stg = src[((it + s) & 7) * 512 + tid]; FENCE(); }
+            if (D && (P == 0 || (P == 2 && (w >> 2) == 1) || (P == 3 && (w & 1) == 1))) { DMA(); FENCE(); }
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + tid] = s;
+    if (lane == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+}
+
+template <bool R, bool B, bool D, int P = 0>
+static void run(const char *name, int waves, const uint4 *src, float *out, long long *cyc) {
+    const int blocks = 256;
+    CK(hipMemset(cyc, 0, blocks * 8 * sizeof(long long)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_rate<R, B, D, P>), dim3(blocks), dim3(64 * waves), 0, 0, src, out, cyc);   // warm-up
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_rate<R, B, D, P>), dim3(blocks), dim3(64 * waves), 0, 0, src, out, cyc);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> h(blocks * 8);
+    CK(hipMemcpy(h.data(), cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    double sum = 0, mx = 0;
+    int n = 0;
+    for (int b = 0; b < blocks; ++b)
+        for (int w = 0; w < waves; ++w) {
+            sum += (double)h[b * 8 + w];
+            if ((double)h[b * 8 + w] > mx) mx = (double)h[b * 8 + w];
+            ++n;
+        }
+    const double per_stage = sum / n / ITER;
+    const int per_simd = waves / 4;
+    const double ideal = 16.0 * 16 * per_simd;
+    const double tflops = (double)blocks * waves * ITER * 16 * 16384.0 / (ms * 1e-3) / 1e12;
+    printf("%-34s waves/SIMD %d  cycles/stage %7.1f (max wave %7.1f)  ideal %5.0f  -> %5.1f %% of the MFMA pipe   %.3f ms  %6.0f TFLOP/s\n", name,
+           per_simd, per_stage, mx / ITER, ideal, 100.0 * ideal / per_stage, ms, tflops);
+}
+
+int main() {
+    uint4 *src;
+    float *out;
+    long long *cyc;
+    CK(hipMalloc(&src, 65536 * 16));
+    CK(hipMemset(src, 0x11, 65536 * 16));
+    CK(hipMalloc(&out, 256 * 512 * sizeof(float)));
+    CK(hipMalloc(&cyc, 256 * 8 * sizeof(long long)));
+    for (int waves = 4; waves <= 8; waves += 4) {
+        run<false, false, false>("bare MFMAs", waves, src, out, cyc);
+        run<true, false, false>("+ 8 ds_read_b128", waves, src, out, cyc);
+        run<false, true, false>("+ barrier", waves, src, out, cyc);
+        run<true, true, false>("+ reads + barrier", waves, src, out, cyc);
+        run<true, true, true>("+ reads + barrier + DMA (= K loop)", waves, src, out, cyc);
+        run<true, true, true, 1>("  DMA early (after MFMA 4), all", waves, src, out, cyc);
+        run<true, true, true, 2>("  DMA early w<4, end w>=4", waves, src, out, cyc);
+        run<true, true, true, 3>("  DMA early even w, end odd w", waves, src, out, cyc);
+        run<true, true, true, 4>("  DMA after 4 (w<4) / after 12 (w>=4)", waves, src, out, cyc);
+        run<true, true, true, 5>("  register-staged copy instead", waves, src, out, cyc);
+    }
+    return 0;
+}
