@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
     for (int it = 0; it < ITER; it += 2) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (B) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (B && P == 6) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (B && P == 7) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (B && P == 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if (B) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if (R) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             MF(s, 0, 0); MF(s, 0, 1); FENCE();
             RD(a[s ^ 1][0], 0); RD(a[s ^ 1][1], 1); FENCE();
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
             if (D && (P == 4 && (w >> 2) == 1)) { DMA(); FENCE(); }
             MF(s, 3, 0); MF(s, 3, 1); MF(s, 3, 2); MF(s, 3, 3); FENCE();
             if (D && P == 5) { stg = src[((it + s) & 7) * 512 + tid]; FENCE(); }
-            if (D && (P == 0 || (P == 2 && (w >> 2) == 1) || (P == 3 && (w & 1) == 1))) { DMA(); FENCE(); }
+            if (D && (P == 0 || (P >= 6 && P <= 8) || (P == 2 && (w >> 2) == 1) || (P == 3 && (w & 1) == 1))) { DMA(); FENCE(); }
         }
     }
     const long long t1 = __builtin_readcyclecounter();
@@ -132,6 +135,9 @@ int main() {
         run<true, true, true, 3>("  DMA early even w, end odd w", waves, src, out, cyc);
         run<true, true, true, 4>("  DMA after 4 (w<4) / after 12 (w>=4)", waves, src, out, cyc);
         run<true, true, true, 5>("  register-staged copy instead", waves, src, out, cyc);
+        run<true, true, true, 6>("  DMA at the end, wait vmcnt(2)", waves, src, out, cyc);
+        run<true, true, true, 7>("  DMA at the end, wait vmcnt(3)", waves, src, out, cyc);
+        run<true, true, true, 8>("  DMA at the end, no vmcnt wait", waves, src, out, cyc);
     }
     return 0;
 }
