@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--cpu-trees", type=int, default=4096)
     ap.add_argument("--train-batch", type=int, default=512, help="config.py:34 batch_size for the training leg (0 = skip)")
     ap.add_argument("--train-unroll", type=int, default=5, help="K (BASELINE configs[4]: 5; config.py:36: 3)")
+    ap.add_argument("--loop-train-steps", type=int, default=20, help="training steps of the whole-loop leg (one generation)")
     return ap.parse_args()
 
 
@@ -189,6 +190,30 @@ def bench_train(args, device, rec):
     return {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
             "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss),
             "bf16_autocast_ms_per_step": dt_amp * 1e3}
+
+
+def bench_loop(args, device, dtype):
+    """BASELINE configs[4] on one rank: a whole generation of muzero_amd.loop (self-play -> replay window -> training
+    steps -> weights published into the serving engine).  With N ranks the same code adds the trajectory all_gather and
+    the one gradient all-reduce per step."""
+    from muzero_amd import config, train as T
+    from muzero_amd.loop import MuZeroLoop
+    T.LOG = None
+    g, steps = args.selfplay_games, args.loop_train_steps
+    config.num_unroll_steps = args.train_unroll
+    lp = MuZeroLoop(g, device=device, infer_dtype=dtype, num_simulations=args.selfplay_sims, window_size=g,
+                    batch_size=args.train_batch, use_graph=not args.no_graph)
+    lp.selfplay.play_games(max_moves=2)   # warm-up: graph capture
+    lp.generation(2)                      # warm-up: optimiser state, kernel selection
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = lp.generation(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    config.num_unroll_steps = 3
+    return {"games": g, "simulations": args.selfplay_sims, "train_steps": steps, "batch": args.train_batch,
+            "unroll_steps": args.train_unroll, "seconds_per_generation": dt, "games_per_sec": g / dt,
+            "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 
 
 def bench_cpu_baseline(args):
@@ -372,6 +397,8 @@ def main():
                                "games_per_sec": g / dts, "simulations_per_sec": g * rec.length * args.selfplay_sims / dts}
             if args.train_batch > 0:
                 out["train"] = bench_train(args, device, rec)
+                del sp, net_sp, rec
+                out["loop"] = bench_loop(args, device, dtype)
         out["cpu_baseline"] = bench_cpu_baseline(args)
     if dist is not None:
         dist.barrier()
