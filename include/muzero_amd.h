@@ -127,6 +127,10 @@ typedef struct mz_search_cfg {
     int32_t bounds_none; /* known_bounds = None */
     int32_t tie_lowest;  /* 0 = reference: max over (score, action) tuples, ties -> HIGHEST index
                             (main.py:145-147); 1 = lowest index (BASELINE.json wording) */
+    int32_t negamax;     /* 0 = reference: ucb_score adds normalize(child.value()) (main.py:159), the value from the
+                            CHILD's mover's point of view -- the two-player sign slip of the MuZero pseudocode: the search
+                            prefers moves that are good for the opponent.  1 = normalize(-child.value()) (non-default) */
+    int32_t reserved;    /* 0 */
 } mz_search_cfg;
 
 /* Node pool for n_trees independent searches of at most max_nodes-1 simulations each, laid out by

@@ -24,7 +24,7 @@ class SearchCfg(C.Structure):
     """mz_search_cfg -- the config.py knobs the search reads (config.py:15,19,22,23,29)."""
     _fields_ = [("pb_c_base", C.c_double), ("pb_c_init", C.c_double), ("discount", C.c_double),
                 ("noise_frac", C.c_double), ("bound_lo", C.c_double), ("bound_hi", C.c_double),
-                ("bounds_none", C.c_int32), ("tie_lowest", C.c_int32)]
+                ("bounds_none", C.c_int32), ("tie_lowest", C.c_int32), ("negamax", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PoolLayout(C.Structure):

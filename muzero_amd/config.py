@@ -49,3 +49,9 @@ lr_decay_steps = 400e3           # config.py:46
 # select_child tie-break.  False = the reference: builtin max over (score, action, child) tuples
 # resolves equal scores to the HIGHEST action index (main.py:145-147).
 tie_break_lowest = False
+# ucb_score's value term.  False = the reference: normalize(child.value()) (main.py:159) with Node.value() kept from the
+# point of view of the player to move AT the child (backpropagate, main.py:182) -- i.e. the parent maximises its
+# OPPONENT's value (the two-player sign slip of the published MuZero pseudocode).  Measured with this engine
+# (profiles/r01/loop_run_*.txt): a network trained through the reference's loop LOSES ~90 % of arena games to its own
+# random initialisation.  True = normalize(-child.value()): the search maximises the mover's own value.
+negamax_value = False

@@ -107,11 +107,12 @@ __device__ __forceinline__ int lo_bit(uint64_t m) { return __ffsll((unsigned lon
 __device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // ucb_score main.py:153-160 for one child record
-__device__ __forceinline__ Mx ucb_score(const ChildRec &r, const PbcRec &pb, const MinMax &mm) {
+__device__ __forceinline__ Mx ucb_score(const ChildRec &r, const PbcRec &pb, const MinMax &mm, bool negamax) {
     const uint32_t n = r.nc & 0xFFFFu;
     const double pb_c = pb.a * (pb.s / (double)(n + 1u));
     const double prior_score = pb_c * r.p;
-    const Mx value = n == 0 ? mx_py(0.0) : mx_t(r.w / (float)n);  // Node.value() reversi.py:248-251
+    Mx value = n == 0 ? mx_py(0.0) : mx_t(r.w / (float)n);  // Node.value() reversi.py:248-251
+    if (negamax && n != 0) value.d = -value.d;                // non-default: the child's value seen from the parent's mover
     return mx_add(mx_py(prior_score), mm_normalize(mm, value));
 }
 
@@ -234,7 +235,7 @@ __device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &
         const ChildRec r = recs[lane];
         const ChildRec r64 = recs[64];
         const PbcRec pb = P.pbc[np];
-        const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
         const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
         if (lane == 0) P.path[tbase + depth] = PathRec{(uint16_t)node, (uint8_t)a, 0};
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
             else if (lane == pa) { r.nc = pnc; r.w = pw; }
         }
         const PbcRec pb = P.pbc[np];
-        const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
         const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
         if (lane == 0) P.path[tbase + level] = PathRec{(uint16_t)node, (uint8_t)a, 0};
@@ -552,7 +553,7 @@ __global__ void __launch_bounds__(64) k_node_scores(Pool P, mz_search_cfg cfg, c
     const ChildRec *recs = P.stats + (tbase + node) * MZ_ACTIONS;
     const ChildRec r = recs[lane], r64 = recs[64];
     const PbcRec pb = P.pbc[np];
-    const Mx s = ucb_score(r, pb, mm), s64 = ucb_score(r64, pb, mm);
+    const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
     const int a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, cfg.tie_lowest != 0);
     if (lane == 0) action_out[t] = a;
     if (score_out) {

@@ -24,7 +24,8 @@ def search_cfg(cfg=None):
     return L.SearchCfg(pb_c_base=float(c.pb_c_base), pb_c_init=float(c.pb_c_init), discount=float(c.discount),
                        noise_frac=float(c.root_exploration_fraction), bound_lo=float(kb[0]) if kb else 0.0,
                        bound_hi=float(kb[1]) if kb else 0.0, bounds_none=int(kb is None),
-                       tie_lowest=int(bool(getattr(c, "tie_break_lowest", False))))
+                       tie_lowest=int(bool(getattr(c, "tie_break_lowest", False))),
+                       negamax=int(bool(getattr(c, "negamax_value", False))), reserved=0)
 
 
 class BatchedMCTS:

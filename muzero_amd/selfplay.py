@@ -66,7 +66,8 @@ class GameRecords:
 
 
 class SelfPlayEngine:
-    def __init__(self, n_games, net, num_simulations=None, device="cuda", use_graph=True, seed=1261, cfg=None):
+    def __init__(self, n_games, net, num_simulations=None, device="cuda", use_graph=True, seed=1261, cfg=None, graph_steps=None):
+        """graph_steps: simulation steps captured per hipGraph (default: all S - 1 of a search in ONE graph)"""
         self.cfg = cfg or config
         self.n = int(n_games)
         self.S = int(num_simulations if num_simulations is not None else self.cfg.num_simulations)
@@ -76,6 +77,7 @@ class SelfPlayEngine:
         self.env = BatchedEnv(self.n, device)
         self.mcts = BatchedMCTS(self.n, self.S, self.dtype, device, cfg=self.cfg)
         self.use_graph = use_graph
+        self.graph_steps = graph_steps
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self._graph = None
@@ -116,7 +118,7 @@ class SelfPlayEngine:
         # one graph = `_graph_steps` consecutive simulation steps (every step reads what the previous one wrote, so the
         # chain is just kernel nodes in sequence); replaying one big graph instead of S-1 small ones removes the host
         # launch gap between steps
-        self._graph_steps = max(1, min(self.S - 1, int(getattr(self, "graph_steps", 0)) or (self.S - 1)))
+        self._graph_steps = max(1, min(self.S - 1, int(self.graph_steps or self.S - 1)))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._cap = [self._sim_step() for _ in range(self._graph_steps)]

@@ -47,7 +47,7 @@ def lib():
         L.mzo_tree_new.argtypes = [C.c_int]
         L.mzo_tree_free.argtypes = [p]
         L.mzo_tree_config.argtypes = [p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
-                                      C.c_double, C.c_int]
+                                      C.c_double, C.c_int, C.c_int]
         L.mzo_ucb_score_probe.restype = C.c_double
         L.mzo_ucb_score_probe.argtypes = [p, C.c_int, C.c_int, p]
         L.mzo_root_init.argtypes = [p, C.c_int, u64, C.c_int, p, p]
@@ -149,11 +149,11 @@ def make_image(hist_white, hist_black, state_index):
 # ---------------------------------------------------------------------------------------------
 class Tree:
     def __init__(self, max_sims, pb_c_base=19652, pb_c_init=1.25, discount=1.0, known_bounds=(-1, 1),
-                 noise_frac=0.25, tie_lowest=False):
+                 noise_frac=0.25, tie_lowest=False, negamax=False):
         self.h = lib().mzo_tree_new(max_sims)
         lo, hi = known_bounds if known_bounds is not None else (0.0, 0.0)
         lib().mzo_tree_config(self.h, pb_c_base, pb_c_init, discount, int(known_bounds is None), lo, hi, noise_frac,
-                              int(tie_lowest))
+                              int(tie_lowest), int(negamax))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -123,8 +123,9 @@ def _roots(n, seed):
     return e, hw, hb, lens.astype(np.int32)
 
 
-@pytest.mark.parametrize("n,S,mode,tie_lowest", [(4096, 50, "hash", False), (512, 100, "sat", False), (512, 60, "hash", True)])
-def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest):
+@pytest.mark.parametrize("n,S,mode,tie_lowest,negamax", [(4096, 50, "hash", False, False), (512, 100, "sat", False, False),
+                                                         (512, 60, "hash", True, False), (512, 60, "hash", False, True)])
+def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest, negamax):
     """BASELINE config 3 size (4096 trees x 50 sims) on HashNet, fused backup+select kernel:
     every tree's visits / W / root value / per-sim leaf identical to the C oracle."""
     from muzero_amd import env as menv
@@ -138,7 +139,7 @@ def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest):
     for g in range(n):
         acts = [a for a in range(64) if (int(e.legal[g]) >> a) & 1] or [64]
         noise[g, acts] = rng.dirichlet([0.03] * len(acts))
-    cfg = Cfg(tie_break_lowest=tie_lowest)
+    cfg = Cfg(tie_break_lowest=tie_lowest, negamax_value=negamax)
     m = BatchedMCTS(n, S, cfg=cfg)
     m.root_init(dev(e.to_play), dev(e.legal), p0.contiguous(), h0.contiguous(), dev(noise))
     leaf_a = np.zeros((n, S), np.uint8); depth = np.zeros((n, S), np.int32)
@@ -156,7 +157,7 @@ def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest):
     imgs = img.cpu().numpy()
     bad = 0
     for g in range(n):
-        t = O.Tree(S, tie_lowest=tie_lowest)
+        t = O.Tree(S, tie_lowest=tie_lowest, negamax=negamax)
         _, odepth, oleaf = t.search_hashnet(e.to_play[g], e.legal[g], int(e.legal[g] == 0), noise[g], R.hashnet_image_hash(imgs[g]), R.MODES[mode], S)
         ov, ow, op, orn, orv = t.root_stats()
         ok = ((visits[g] == ov).all() and wsum[g].view(np.uint32).tolist() == ow.view(np.uint32).tolist() and (prior[g] == op).all()

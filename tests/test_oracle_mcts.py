@@ -1,6 +1,7 @@
 """Pin the C oracle's tree search against fixtures generated from the imported reference
 (tests/golden/make_golden.py: run_mcts / select_child / ucb_score / expand_node / backpropagate /
 add_exploration_noise / select_action, with HashNet or recorded real-network outputs).  CPU only."""
+import ctypes
 import os
 
 import numpy as np
@@ -112,6 +113,33 @@ def test_tie_break_is_highest_index_at_first_simulation(fx):
     t2 = O.Tree(4, tie_lowest=True)
     t2.root_init(-1, fx["legal"][i], 0, fx["root_policy"][i], None)
     assert t2.select()[2] == 19
+
+
+def test_negamax_switch_flips_the_value_term_only(fx):
+    """non-default config.negamax_value: ucb_score adds normalize(-child.value()) instead of the reference's
+    normalize(child.value()) (main.py:159); prior term, visit accounting and unvisited children are untouched"""
+    i = int(np.nonzero((fx["steps"] == 0) & (fx["kind"] == 0))[0][0])
+    S = 12
+    ref, neg = O.Tree(S), O.Tree(S, negamax=True)
+    img = R.hashnet_image_hash(fx["image"][i])
+    for t in (ref, neg):
+        t.search_hashnet(-1, int(fx["legal"][i]), 0, None, img, int(fx["mode"][i]), S)
+        assert t.root_stats()[0].clip(min=0).sum() == S
+    # identical until a visited child's value enters a comparison, then the two searches part
+    assert (ref.root_stats()[0] != neg.root_stats()[0]).any()
+    c = ctypes.c_int(0)
+    for a in (19, 26, 37, 44):
+        sr = O.lib().mzo_ucb_score_probe(ref.h, 0, a, ctypes.byref(c))
+        assert np.isfinite(sr)
+    # a single visited child: scores differ by exactly the sign of the value inside normalize
+    t1, t2 = O.Tree(2), O.Tree(2, negamax=True)
+    for t in (t1, t2):
+        t.search_hashnet(-1, int(fx["legal"][i]), 0, None, img, int(fx["mode"][i]), 1)
+    a = int(np.argmax(t1.root_stats()[0]))
+    s1 = O.lib().mzo_ucb_score_probe(t1.h, 0, a, ctypes.byref(c))
+    s2 = O.lib().mzo_ucb_score_probe(t2.h, 0, a, ctypes.byref(c))
+    v = float(t1.root_stats()[1][a])   # value_sum of the once-visited child = its value
+    assert v != 0 and abs((s1 - s2) - v) < 1e-6   # normalize over (-1, 1): (v+1)/2 - (-v+1)/2 = v
 
 
 def test_whole_games(golden_dir):
