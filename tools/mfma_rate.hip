@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
         b[0][i] = b[1][i] = *reinterpret_cast<const bf16x8 *>(base + (4 + i) * 1024);
     }
     __syncthreads();
+    uint4 stg2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};   // P == 10: the same, loaded two stages ahead (no latency exposed)
     uint4 stg = make_uint4(0, 0, 0, 0);   // P == 5: register-staged copy (global_load_dwordx4 now, ds_write_b128 one stage later)
     const long long t0 = __builtin_readcyclecounter();
 #define MF(s, i, j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[4 * i + j], 0, 0, 0)
@@ -72,6 +73,12 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
             if (D && (P == 4 && (w >> 2) == 1)) { DMA(); FENCE(); }
             MF(s, 3, 0); MF(s, 3, 1); MF(s, 3, 2); MF(s, 3, 3); FENCE();
             if (D && P == 5) { stg = src[((it + s) & 7) * 512 + tid]; FENCE(); }
+            if (D && P == 10) {
+                *reinterpret_cast<uint4 *>(lds + 131072 + ((it + s) & 3) * 8192 + tid * 16) = stg2[s];
+                FENCE();
+                stg2[s] = src[((it + s) & 7) * 512 + tid];
+                FENCE();
+            }
             if (D && (P == 0 || (P >= 6 && P <= 8) || (P == 2 && (w >> 2) == 1) || (P == 3 && (w & 1) == 1))) { DMA(); FENCE(); }
         }
     }
@@ -135,6 +142,7 @@ int main() {
         run<true, true, true, 3>("  DMA early even w, end odd w", waves, src, out, cyc);
         run<true, true, true, 4>("  DMA after 4 (w<4) / after 12 (w>=4)", waves, src, out, cyc);
         run<true, true, true, 5>("  register-staged copy instead", waves, src, out, cyc);
+        run<true, true, true, 10>("  register-staged, 2 stages ahead, end", waves, src, out, cyc);
         run<true, true, true, 6>("  DMA at the end, wait vmcnt(2)", waves, src, out, cyc);
         run<true, true, true, 7>("  DMA at the end, wait vmcnt(3)", waves, src, out, cyc);
         run<true, true, true, 8>("  DMA at the end, no vmcnt wait", waves, src, out, cyc);
