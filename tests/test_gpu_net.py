@@ -140,3 +140,45 @@ def test_hip_tower_weight_publish():
     fresh = InferenceEngine(new, 8, torch.bfloat16, tower="hip")
     vf, pf, hf = fresh.recurrent(x10)
     assert not torch.equal(h0, h1) and torch.equal(h1, hf) and torch.equal(v1, vf) and torch.equal(p1, pf)
+
+
+def test_hip_tower_f32_hidden_and_argument_checks():
+    """mz_tower_forward / mz_inference_forward through the C ABI: the f32 hidden output is the bf16 one before its final
+    rounding; n = 0 is a no-op; bad arguments are refused with a message instead of launching"""
+    from muzero_amd import _lib as L
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(3)
+    n = 37
+    eng = InferenceEngine(Network(), n, torch.bfloat16, tower="hip")
+    x10 = torch.rand(n, 10, 8, 8, device="cuda").to(torch.bfloat16)
+    pk, heads = eng._packs["dyn"], eng._packs["heads"]
+    h16 = eng._tower_hip("dyn", x10)
+    h32 = torch.full((n, 8, 8, 8), float("nan"), dtype=torch.float32, device="cuda")
+    L.call("mz_tower_forward", L.C.byref(pk["struct"]), L.dptr(x10), L.dptr(h32), L.MZ_F32, n, L.current_stream())
+    assert torch.equal(h32.to(torch.bfloat16), h16) and not torch.equal(h32, h16.float())
+    # heads fed by the f32 hidden: same value/policy as module heads on that f32 hidden
+    value = torch.empty(n, dtype=torch.float32, device="cuda")
+    policy = torch.empty((n, 65), dtype=torch.float32, device="cuda")
+    L.call("mz_inference_forward", L.C.byref(pk["struct"]), L.C.byref(heads["struct"]), L.dptr(x10), L.dptr(h32), L.MZ_F32,
+           L.dptr(value), L.dptr(policy), n, L.current_stream())
+    ref = Network().cuda()
+    ref.load_state_dict({k: v.float() for k, v in eng.net.state_dict().items()})
+    with torch.no_grad():
+        p_ref, v_ref = ref.prediction(h32)
+    assert (policy - p_ref).abs().max().item() < 2e-5 and (value - v_ref.reshape(-1)).abs().max().item() < 2e-5
+    # n = 0: nothing is launched, nothing is written
+    sentinel = h32.clone()
+    L.call("mz_tower_forward", L.C.byref(pk["struct"]), L.dptr(x10), L.dptr(h32), L.MZ_F32, 0, L.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(h32, sentinel)
+    # refused: unsupported hidden dtype, null input, negative n, null heads
+    for args in ((L.C.byref(pk["struct"]), L.dptr(x10), L.dptr(h32), L.MZ_F16, n, L.current_stream()),
+                 (L.C.byref(pk["struct"]), None, L.dptr(h32), L.MZ_F32, n, L.current_stream()),
+                 (L.C.byref(pk["struct"]), L.dptr(x10), L.dptr(h32), L.MZ_F32, -1, L.current_stream())):
+        with pytest.raises(L.MzError):
+            L.call("mz_tower_forward", *args)
+    with pytest.raises(L.MzError):
+        L.call("mz_inference_forward", L.C.byref(pk["struct"]), None, L.dptr(x10), L.dptr(h32), L.MZ_F32, L.dptr(value), L.dptr(policy), n,
+               L.current_stream())
+    with pytest.raises(L.MzError):
+        eng.recurrent(x10.float())   # the wrapper refuses a non-bf16 input
