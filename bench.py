@@ -111,6 +111,9 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(end) / iters
 
 
+ENV_VALU_INSTR, ENV_VALU_CYCLES = 373, 1072
+
+
 def bench_env(args, device):
     from muzero_amd.env import BatchedEnv
     n = args.env_games
@@ -145,7 +148,13 @@ def bench_env(args, device):
         "roofline_env": {"kernel": "k_env_step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step"), "bytes_per_step": ENV_BYTES_PER_STEP,
                          "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP,
-                         "us_per_launch": ms_step * 1e3},
+                         "us_per_launch": ms_step * 1e3,
+                         # the env's floor is its integer ALU work, so the VALU rate is reported beside the GB/s.
+                         # Static count from the gfx950 ISA of k_env_step: 373 VALU instructions per wave-step, 98 of them
+                         # half-rate 64-bit shifts -> ~1070 issue cycles per wave (measured rates: 2.4 / 4.2 cycles, env_kernels.hip)
+                         "valu": {"instructions_per_wave_step": ENV_VALU_INSTR, "issue_cycles_per_wave_step": ENV_VALU_CYCLES,
+                                  "wave_instructions_per_sec": n / 64 * ENV_VALU_INSTR / (ms_step * 1e-3),
+                                  "busy_frac_at_2.4GHz": n / 64 * ENV_VALU_CYCLES / 1024 / 2.4e9 / (ms_step * 1e-3)}},
     }
 
 
