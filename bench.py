@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tower", default="auto", choices=["auto", "hip", "miopen"], help="inference path (auto = hip for bf16)")
     ap.add_argument("--env-games", type=int, default=1 << 20)
-    ap.add_argument("--selfplay-games", type=int, default=1024)
+    ap.add_argument("--selfplay-games", type=int, default=4096)
     ap.add_argument("--selfplay-sims", type=int, default=50)
     ap.add_argument("--skip-extras", action="store_true", help="only the timed MCTS leg")
     ap.add_argument("--cpu-trees", type=int, default=4096)
