@@ -314,11 +314,15 @@ int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int
 
 /* Prediction heads (network.py:79-111) fused behind the tower: 1x1 conv 8->2 + ReLU + Flatten +
  * Linear(128,128) + ReLU + Linear(128,65) + Softmax (policy); 1x1 conv 8->2 + ReLU + Flatten +
- * Linear(128,1) + Tanh (value).  f32 weights and arithmetic; Linear matrices TRANSPOSED ([in][out]). */
+ * Linear(128,1) + Tanh (value).  f32 arithmetic.  The two Linear matrices are bf16 (the serving network's weights are
+ * bf16 values: nothing is lost, and the heads read half the bytes), TRANSPOSED and packed in input PAIRS:
+ * element [r][out] is one 32-bit word {low half: W[out][2r], high half: W[out][2r+1]}.  Everything else is f32. */
 typedef struct mz_heads_weights {
     const float *pc_w, *pc_b;   /* policy_head.0: [2][8], [2] */
-    const float *p1_wt, *p1_b;  /* policy_head.3: [128 in][128 out], [128] */
-    const float *p2_wt, *p2_b;  /* policy_head.5: [128 in][65 out], [65] */
+    const uint32_t *p1_wt;      /* policy_head.3 weight: bf16 pairs [64 input pairs][128 out] */
+    const float *p1_b;          /* [128] */
+    const uint32_t *p2_wt;      /* policy_head.5 weight: bf16 pairs [64 input pairs][65 out] */
+    const float *p2_b;          /* [65] */
     const float *vc_w, *vc_b;   /* value_head.0: [2][8], [2] */
     const float *v1_w, *v1_b;   /* value_head.3: [128], [1] */
 } mz_heads_weights;

@@ -49,7 +49,7 @@ class TowerWeights(C.Structure):
 
 
 class HeadsWeights(C.Structure):
-    """mz_heads_weights -- f32 device pointers of the prediction heads"""
+    """mz_heads_weights -- device pointers of the prediction heads (f32; p1_wt / p2_wt bf16 input pairs)"""
     _fields_ = [(k, C.c_void_p) for k in ("pc_w", "pc_b", "p1_wt", "p1_b", "p2_wt", "p2_b", "vc_w", "vc_b", "v1_w", "v1_b")]
 
 

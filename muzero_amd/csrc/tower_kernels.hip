@@ -63,11 +63,14 @@ struct Tower {
     long long *stamps;     // diagnostics: [blocks][24] s_memtime stamps at the phase boundaries (null = off)
 };
 
-// prediction heads (network.py:79-111), f32 weights, FC matrices stored [in][out] so lanes (= outputs) read coalesced
+// prediction heads (network.py:79-111): FC matrices as bf16 input pairs [in / 2][out] (one dword = inputs 2r, 2r + 1 of one
+// output) so lanes (= outputs) read coalesced and a thread's 32 inputs are 16 dwords; everything else f32
 struct Heads {
     const float *pc_w, *pc_b;    // policy 1x1 conv [2][8], [2]
-    const float *p1_wt, *p1_b;   // Linear(128,128) as [in 128][out 128], [128]
-    const float *p2_wt, *p2_b;   // Linear(128,65)  as [in 128][out 65],  [65]
+    const uint32_t *p1_wt;       // Linear(128,128) as bf16 pairs [64][out 128]
+    const float *p1_b;           // [128]
+    const uint32_t *p2_wt;       // Linear(128,65)  as bf16 pairs [64][out 65]
+    const float *p2_b;           // [65]
     const float *vc_w, *vc_b;    // value 1x1 conv [2][8], [2]
     const float *v1_w, *v1_b;    // Linear(128,1) [128], [1]
     float *value, *policy;       // outputs (n), (n,65); null = heads off
@@ -167,7 +170,7 @@ typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
 template <bool RES>
 __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, f32x4 (&bv)[4],
-                                          const float *__restrict__ bias_next, int tid, uint32_t vm, const Tower &tw, int stamp_id) {
+                                          const float *__restrict__ bias_next, const uint4 *__restrict__ tail_dma, int tid, uint32_t vm, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
     // the accumulators START at the bias (bv: the lane's 16 values, channels cobase + 16 i + 4 kc + 0..3, requested during
@@ -280,6 +283,18 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     }
 
     MZ_STAMP(tw, stamp_id);
+    // behind the last mid layer: the LAST conv layer's 36 weight stages (36 KB, already in LDS order) go into the T image by
+    // LDS-DMA now, under this epilogue.  T is free: after the K loop's last barrier no wave reads it any more (stage 35's
+    // fragments were read during stage 34, and the "tap 9" prefetch reads the zero block).
+    if (tail_dma) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int piece = w + 8 * k;   // 1 KB pieces, wave-uniform
+            if (piece < LAST_W_BYTES / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tail_dma + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)(lds + OFF_T + piece * 1024), 16, 0, 0);
+        }
+    }
     // the next layer's bias: two thousand cycles of epilogue ahead of its first use
     if (bias_next) {
 #pragma unroll
@@ -395,16 +410,32 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
     __syncthreads();
 }
 
-struct HeadRegs { float w1[32], w2[32], pv; };
+struct HeadRegs { uint32_t w1[16], w2[16]; float pv; };   // w: bf16 pairs {input 2i (low), input 2i + 1 (high)}
+__device__ __forceinline__ float pair_lo(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float pair_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
+// 32-input dot product of a thread's weight pairs with 32 f32 features in LDS, on packed fp32 FMAs (v_pk_fma_f32: two
+// lanes of an even/odd-input accumulator pair per instruction; the library is built with -ffp-contract=off, so the FMA
+// is spelled out).  The Linear layers are VALU-bound: this is a quarter of the instructions of separate mul + add.
+__device__ __forceinline__ float dot32(const uint32_t (&wp)[16], const float *x) {
+    const f32x4 *f = reinterpret_cast<const f32x4 *>(x);
+    f32x2 a = {0.0f, 0.0f};
+#pragma unroll
+    for (int i4 = 0; i4 < 8; ++i4) {
+        const f32x4 v = f[i4];
+        a = __builtin_elementwise_fma(f32x2{pair_lo(wp[2 * i4]), pair_hi(wp[2 * i4])}, f32x2{v[0], v[1]}, a);
+        a = __builtin_elementwise_fma(f32x2{pair_lo(wp[2 * i4 + 1]), pair_hi(wp[2 * i4 + 1])}, f32x2{v[2], v[3]}, a);
+    }
+    return a[0] + a[1];
+}
 
 // every global read of the heads, issued BEFORE the last conv layer so its latency hides under that layer's MFMAs
 __device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadRegs &hr) {
     const int grp = tid >> 7, k = tid & 127;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) hr.w1[i] = hd.p1_wt[(32 * grp + i) * 128 + k];
+    for (int i = 0; i < 16; ++i) hr.w1[i] = hd.p1_wt[(16 * grp + i) * 128 + k];
     const int k2 = k < MZ_ACTIONS ? k : 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) hr.w2[i] = hd.p2_wt[(32 * grp + i) * MZ_ACTIONS + k2];
+    for (int i = 0; i < 16; ++i) hr.w2[i] = hd.p2_wt[(16 * grp + i) * MZ_ACTIONS + k2];
     float pv = 0.0f;   // one small parameter per thread
     if (tid < 16) pv = hd.pc_w[tid];
     else if (tid < 18) pv = hd.pc_b[tid - 16];
@@ -426,17 +457,10 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
                                            int64_t board0, int64_t n_boards, int tid, float (&hv)[2][4]) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     char *wl = lds + OFF_T;
-    // vmcnt retires in order: this layer's weights are requested FIRST, the heads' 65 reads behind them, so storing the
-    // weights to LDS waits only for the weights and the heads' reads stay in flight under the MFMAs below (raw barrier:
-    // __syncthreads() would drain them)
-    uint4 wreg[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) wreg[i] = (i * 512 + tid) < LAST_W_BYTES / 16 ? tw.w_last[i * 512 + tid] : make_uint4(0, 0, 0, 0);
+    // this layer's weights were sent to the T image by LDS-DMA during the last mid layer's epilogue (layer_mid, tail_dma):
+    // retire every wave's pieces, then the heads' 65 global reads are requested and stay in flight under the MFMAs below
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (hd.policy) heads_prefetch(hd, tid, hr);
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-        if ((i * 512 + tid) < LAST_W_BYTES / 16) *reinterpret_cast<uint4 *>(wl + (i * 512 + tid) * 16) = wreg[i];
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     acc16_t acc[2] = {acc16_t{0.0f, 0.0f, 0.0f, 0.0f}, acc16_t{0.0f, 0.0f, 0.0f, 0.0f}};
     const int waddr = c16 * 64 + ((kc ^ ((0x78 >> (((c16 >> 2) & 3) * 2)) & 3)) << 4);
     const int x = p16 & 7, y0 = p16 >> 3, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
@@ -508,8 +532,8 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const Hea
           *s_v1_b = prm + 368;
     const int w = tid >> 6, lane = tid & 63;
     const int grp = tid >> 7, k = tid & 127;   // input group / board (wave-uniform), output column
-    const float(&w1)[32] = hr.w1;
-    const float(&w2)[32] = hr.w2;
+    const uint32_t(&w1)[16] = hr.w1;
+    const uint32_t(&w2)[16] = hr.w2;
     __syncthreads();  // every wave is done reading X
     prm[tid] = hr.pv;
     if (lane < 32) {   // layer_last's D layout: lane -> cell col_cell(lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
@@ -535,14 +559,7 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const Hea
     {   // Linear(128,128): partial sums over inputs 32 grp .. 32 grp + 31, all 4 boards
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const f32x4 *f = reinterpret_cast<const f32x4 *>(fp + b * 128 + 32 * grp);
-            float a = 0.0f;
-#pragma unroll
-            for (int i4 = 0; i4 < 8; ++i4) {
-                const f32x4 x = f[i4];
-                a += w1[4 * i4] * x[0] + w1[4 * i4 + 1] * x[1] + w1[4 * i4 + 2] * x[2] + w1[4 * i4 + 3] * x[3];
-            }
-            part[(grp * 4 + b) * 128 + k] = a;
+            part[(grp * 4 + b) * 128 + k] = dot32(w1, fp + b * 128 + 32 * grp);
         }
         if (w < 4) {   // value Linear(128,1): wave w = board w
             float v = s_v1_w[lane] * fv[w * 128 + lane] + s_v1_w[lane + 64] * fv[w * 128 + lane + 64];
@@ -558,14 +575,7 @@ __device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const Hea
     if (k < MZ_ACTIONS) {   // Linear(128,65) partial sums
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const f32x4 *f = reinterpret_cast<const f32x4 *>(h1 + b * 128 + 32 * grp);
-            float a = 0.0f;
-#pragma unroll
-            for (int i4 = 0; i4 < 8; ++i4) {
-                const f32x4 x = f[i4];
-                a += w2[4 * i4] * x[0] + w2[4 * i4 + 1] * x[1] + w2[4 * i4 + 2] * x[2] + w2[4 * i4 + 3] * x[3];
-            }
-            part[(grp * 4 + b) * 128 + k] = a;
+            part[(grp * 4 + b) * 128 + k] = dot32(w2, h1 + b * 128 + 32 * grp);
         }
     }
     __syncthreads();
@@ -608,9 +618,10 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
     for (int blk = 0; blk < 3; ++blk) {
         const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 512;
         const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 512;
-        layer_mid<false>(lds, OFF_X, OFF_T, w0, bv, tw.b_mid + (2 * blk + 1) * 128, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
+        layer_mid<false>(lds, OFF_X, OFF_T, w0, bv, tw.b_mid + (2 * blk + 1) * 128, nullptr, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
         MZ_STAMP(tw, 4 + 4 * blk);
-        layer_mid<true>(lds, OFF_T, OFF_X, w1, bv, blk < 2 ? tw.b_mid + (2 * blk + 2) * 128 : nullptr, tid, vm, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
+        layer_mid<true>(lds, OFF_T, OFF_X, w1, bv, blk < 2 ? tw.b_mid + (2 * blk + 2) * 128 : nullptr, blk == 2 ? tw.w_last : nullptr, tid, vm, tw,
+                         5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
     float hv[2][4];
