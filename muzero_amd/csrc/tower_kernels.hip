@@ -340,7 +340,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
     char *in = lds + OFF_T;
     char *wf = lds + OFF_T + TILE_POS * 32;
-    f32x4 bv[2][4];   // requested now, first touched in the epilogue
+    f32x4 bv[2][4];   // requested now; the accumulators start at the bias (D rows of a 32x32 tile: 8 g + 4 h + k)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -371,7 +371,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.0f;
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = bv[i][k >> 2][k & 3];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
@@ -398,12 +398,9 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
             for (int j = 0; j < 2; ++j) {
                 const int q = posbase + 32 * j + r;
                 char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[i][j][4 * g + k] + bv[i][g][k], 0.0f);
-                uint2 o;
-                o.x = pack_bf16(v[0], v[1]);
-                o.y = pack_bf16(v[2], v[3]);
+                uint2 o;   // round, then ReLU on the packed pair (as layer_mid)
+                o.x = relu_bf16x2(pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]));
+                o.y = relu_bf16x2(pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
                 *reinterpret_cast<uint2 *>(p) = o;
             }
         }

@@ -43,12 +43,17 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
     __syncthreads();
     uint4 stg2[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};   // P == 10: the same, loaded two stages ahead (no latency exposed)
     uint4 stg = make_uint4(0, 0, 0, 0);   // P == 5: register-staged copy (global_load_dwordx4 now, ds_write_b128 one stage later)
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;   // LDS byte address of the array
     const long long t0 = __builtin_readcyclecounter();
 #define MF(s, i, j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[4 * i + j], 0, 0, 0)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DMA()                                                                                                                        \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((it + s) & 7) * 512 + tid),            \
                                      (__attribute__((address_space(3))) void *)(lds + 131072 + ((it + s) & 3) * 8192 + w * 1024), 16, 0, 0)
+// P == 11: the same DMA in its SGPR-base + 32-bit lane offset form (no 64-bit address VGPR pair)
+#define DMA_SADDR()                                                                                                                 \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(tid * 16)),                         \
+                 "s"(src + ((it + s) & 7) * 512), "s"(__builtin_amdgcn_readfirstlane((int)(lds_base + 131072 + ((it + s) & 3) * 8192 + w * 1024))) : "memory")
 #define RD(dst, off) if (R) dst = *reinterpret_cast<const bf16x8 *>(base + (off) * 1024)
 #pragma unroll 1
     for (int it = 0; it < ITER; it += 2) {
@@ -73,6 +78,7 @@ __global__ void __launch_bounds__(512) k_rate(const uint4 *__restrict__ src, flo
             if (D && (P == 4 && (w >> 2) == 1)) { DMA(); FENCE(); }
             MF(s, 3, 0); MF(s, 3, 1); MF(s, 3, 2); MF(s, 3, 3); FENCE();
             if (D && P == 5) { stg = src[((it + s) & 7) * 512 + tid]; FENCE(); }
+            if (D && P == 11) { DMA_SADDR(); FENCE(); }
             if (D && P == 10) {
                 *reinterpret_cast<uint4 *>(lds + 131072 + ((it + s) & 3) * 8192 + tid * 16) = stg2[s];
                 FENCE();
@@ -143,6 +149,7 @@ int main() {
         run<true, true, true, 4>("  DMA after 4 (w<4) / after 12 (w>=4)", waves, src, out, cyc);
         run<true, true, true, 5>("  register-staged copy instead", waves, src, out, cyc);
         run<true, true, true, 10>("  register-staged, 2 stages ahead, end", waves, src, out, cyc);
+        run<true, true, true, 11>("  DMA, SGPR base + 32-bit offset form", waves, src, out, cyc);
         run<true, true, true, 6>("  DMA at the end, wait vmcnt(2)", waves, src, out, cyc);
         run<true, true, true, 7>("  DMA at the end, wait vmcnt(3)", waves, src, out, cyc);
         run<true, true, true, 8>("  DMA at the end, no vmcnt wait", waves, src, out, cyc);
