@@ -31,4 +31,3 @@ for i, n in enumerate(names):
 print("%-18s mean %9.0f" % ("total per block", tot.mean()))
 rt = (s[:, 18] - s[:, 17])
 print("in-kernel clock: %.3f GHz (shader cycles / 100 MHz real-time ticks, median over blocks)" % float((tot / rt).median() * 0.1))
-print("kernel span (max end - min start): %.0f ticks" % (s[:, 16].max() - s[:, 0].min()))
