@@ -225,7 +225,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
         for (int ss = 0; ss < 12; ++ss) {
             // all but the youngest DMA (stage st + 2, issued one iteration ago) have landed: stage st + 1 is complete
-#ifndef MZ_EXP_NOBARRIER
+#ifndef MZ_EXP_NOBARRIER   // diagnostic builds only (-DMZ_EXP_NOBARRIER / -DMZ_EXP_NOWEIGHTS: wrong results, used with tools/tower_stamps.py to price the barrier and the DMA)
             asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
             // hand-ordered issue, fenced with sched_barrier(0) (hipcc otherwise sinks the prefetch reads to their use and
