@@ -63,6 +63,7 @@ def play_games(black_net, white_net, n_games, num_simulations=NUM_SIMULATIONS, t
     actions = torch.zeros((T, n), dtype=torch.uint8, device=dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
+    bad = torch.zeros(n, dtype=torch.bool, device=dev)
     for t in range(T):
         eng = engines[id(black_net if t % 2 == 0 else white_net)]  # BLACK moves on even steps (reversi.py:54,137,176)
         image = controller_image(hw, hb, t, n, eng.dtype)
@@ -70,9 +71,12 @@ def play_games(black_net, white_net, n_games, num_simulations=NUM_SIMULATIONS, t
         visits, _ = eng.search(image, noise=None)   # expand_node + run_mcts, no add_exploration_noise (test.py:37-41)
         ut = u[t].contiguous() if u is not None else torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
         a = softmax_sample(visits, temperature, ut)
-        env.step(a)   # finished games report MZ_ST_DONE and stay untouched
+        _, status = env.step(a)   # finished games report MZ_ST_DONE and stay untouched
+        bad |= status == L.ST_ILLEGAL
         actions[t].copy_(a)
         hw[t + 1], hb[t + 1] = env.white, env.black
+    if int(bad.sum()):   # the reference would assert (reversi.py:143-144)
+        raise L.MzError("arena: %d games were handed an illegal action" % int(bad.sum()))
     pop = lambda x: ((x.unsqueeze(-1) >> torch.arange(64, device=dev)) & 1).sum(-1).to(torch.int32).cpu()  # noqa: E731
     return ArenaResult(actions, pop(env.white), pop(env.black), env.done.clone().cpu())
 

@@ -324,7 +324,7 @@ def expand_node(node: Node, actions: List[Action], network_output):
         tree.root_inputs = dict(to_play=torch.tensor([node._player.value], dtype=torch.int8, device=d),
                                 legal=torch.tensor([legal], dtype=torch.int64, device=d),
                                 pass_ok=torch.tensor([int(64 in idx)], dtype=torch.uint8, device=d),
-                                policy=policy, hidden=hidden, actions=idx)
+                                policy=policy, hidden=hidden, actions=idx, order=[a.index for a in actions])
         node._tree = tree
         _root_init(tree, None)
         return
@@ -353,7 +353,10 @@ def add_exploration_noise(node: Node):
     tree = node._tree
     if tree is None or node._ref is not None or node.visit_count != 0:
         raise NotImplementedError("add_exploration_noise applies to a freshly expanded root (main.py:82-83)")
-    acts = tree.root_inputs["actions"]
+    # the i-th draw goes to the i-th action of the list expand_node was given (= root.children order in the reference,
+    # main.py:192-196), so a caller that passes the reference's own (set-ordered) legal list consumes the np.random stream
+    # exactly as the reference does; the prior normalisation still sums in ascending action order
+    acts = tree.root_inputs["order"]
     drawn = np.random.dirichlet([config.root_dirichlet_alpha] * len(acts))
     noise = np.zeros((1, 65), np.float64)
     noise[0, acts] = drawn

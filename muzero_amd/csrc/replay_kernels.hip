@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(64) k_replay_save(mz_replay rb, int slot0, con
     const int g = blockIdx.x, lane = threadIdx.x;
     const int T = rb.max_moves;
     const int64_t slot = (slot0 + g) % rb.window;
-    const int len = length ? length[g] : length_all;
+    int len = length ? length[g] : length_all;
+    len = len < 0 ? 0 : (len > T ? T : len);   // a per-game length outside [0, max_moves] must not reach the sampler's indexing
     for (int t = lane; t <= T; t += 64) {
         const bool in = t <= len;  // state_history has len+1 entries
         rb.white[slot * (T + 1) + t] = in ? hw[(int64_t)t * stride + g] : 0ULL;
@@ -60,7 +61,9 @@ __global__ void __launch_bounds__(64) k_replay_sample(mz_replay rb, const int32_
     const int T = rb.max_moves;
     const int64_t slot = slot_in[b];
     const int pos = pos_in[b];
+    if (slot < 0 || slot >= rb.window) return;          // caller bug: leave the sample's rows untouched rather than read out of bounds
     const int len = rb.length[slot];
+    if (pos < 0 || pos + K > len || len > T) return;    // utilities.py:104 draws pos in [0, len - K]
     // Game.make_image(pos) reversi.py:301-312: plane p, cell = lane
     const uint64_t *hw = rb.white + slot * (T + 1), *hb = rb.black + slot * (T + 1);
     float *img = image + (int64_t)b * 576;

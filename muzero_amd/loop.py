@@ -43,9 +43,7 @@ class MuZeroLoop:
         self.optimizer = T.make_optimizer(self.network)
         self.bucket = T.FlatGradBucket(self.network.parameters())
         self.storage = T.SharedStorage(self.network.state_dict())
-        serve = Network()
-        serve.load_state_dict(self.network.state_dict())
-        self.infer = InferenceEngine(serve, games_per_rank, infer_dtype, device=self.device)
+        self.infer = InferenceEngine(self.network, games_per_rank, infer_dtype, device=self.device)   # serves its own copy
         self.selfplay = SelfPlayEngine(games_per_rank, self.infer, num_simulations=num_simulations, device=self.device,
                                        use_graph=use_graph, seed=seed + 7919 * self.rank)
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)

@@ -13,6 +13,8 @@ What is added for the batched engine:
 
 Return contract (network.py:146-163): ``(value (B,1), policy (B,65) softmaxed, hidden (B,8,8,8))``.
 """
+import copy
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -173,7 +175,7 @@ class InferenceEngine:
         self.device = torch.device(device)
         self.batch = int(batch)
         self.dtype = dtype
-        self.net = network.to(self.device).eval()
+        self.net = copy.deepcopy(network).to(self.device).eval()   # the caller's module (fp32 master weights) is left untouched
         if dtype != torch.float32:
             self.net = self.net.to(dtype)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format

@@ -74,6 +74,8 @@ class ReplayBuffer:
             per_game = torch.tensor(host, dtype=torch.int32, device=self.device)
         else:
             host = [int(lengths)] * n
+        if len(host) != n or any(ln < 0 or ln > self.max_moves for ln in host):
+            raise L.MzError("game lengths must be %d values in [0, %d]" % (n, self.max_moves))
         slot0 = self._claim(n)
         L.call("mz_replay_save", L.C.byref(self._rb), slot0, L.dptr(hw), L.dptr(hb), L.dptr(acts), L.dptr(rews), L.dptr(visits),
                L.dptr(rv), L.dptr(per_game), 0 if per_game is not None else host[0], hw.shape[1], n, L.current_stream())

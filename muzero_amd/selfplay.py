@@ -23,7 +23,7 @@ import torch
 from . import _lib as L
 from . import config
 from .env import BatchedEnv, make_image
-from .mcts import BatchedMCTS, select_action
+from .mcts import META_ERROR, BatchedMCTS, select_action
 
 
 class NetworkAdapter:
@@ -160,6 +160,8 @@ class SelfPlayEngine:
         rec = GameRecords(self.n, self.device, T)
         env = self.env
         env.reset()
+        bad = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+        err = torch.zeros(self.n, dtype=torch.bool, device=self.device)
         rec.hist_white[0].copy_(env.white)
         rec.hist_black[0].copy_(env.black)
         for t in range(T):
@@ -169,6 +171,8 @@ class SelfPlayEngine:
                                                                      generator=self.gen)
             action = select_action(visits, t, ut)  # len(action_history) == t for every game
             reward, status = env.step(action)
+            bad |= status == L.ST_ILLEGAL
+            err |= self.mcts.meta()[:, META_ERROR] != 0   # root_init clears the flag, so collect it per move
             rec.actions[t].copy_(action)
             rec.rewards[t].copy_(reward)
             rec.visits[t].copy_(visits)
@@ -177,4 +181,11 @@ class SelfPlayEngine:
             rec.hist_black[t + 1].copy_(env.black)
             rec.length = t + 1
         rec.done = env.done.clone()
+        # one sync per call: a move the env rejected (the reference would assert, reversi.py:143-144) or a tree that ran
+        # out of pool must not flow into the replay window as a silently corrupt trajectory
+        n_bad = int(bad.sum())
+        n_err = int(err.sum())
+        if n_bad or n_err:
+            raise L.MzError("self-play: %d games were handed an illegal action, %d trees flagged an error "
+                            "(non-finite network outputs?)" % (n_bad, n_err))
         return rec

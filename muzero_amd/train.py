@@ -15,6 +15,7 @@ The networks and the optimiser stay PyTorch (north_star); what is build-specific
     identical without a weight broadcast; ``broadcast_weights`` exists for (re)joining ranks / resume.
 """
 import os
+import random
 import time
 
 import torch
@@ -192,8 +193,20 @@ def train_network(network, optimizer, storage, replay_buffer, training_steps=Non
     print('start training')
     losses = []
     steps = int(config.training_steps if training_steps is None else training_steps)
+    world = dist.get_world_size(group) if _dist_on(group) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    if world > 1 and replay_buffer.batch_size % world:
+        raise ValueError("global batch %d is not divisible by %d ranks" % (replay_buffer.batch_size, world))
     for i in range(1, steps + 1):
-        batch = replay_buffer.sample_batch(config.num_unroll_steps)
+        if world > 1:
+            # data parallel: every rank makes the SAME draws (`random` seeded identically on all ranks, main.py:19) and
+            # trains on its slice of them, so N ranks see exactly the global batch one process would (loop.generation)
+            idx = random.sample(range(replay_buffer.buffer_size), replay_buffer.batch_size)   # utilities.py:76
+            pos = [replay_buffer.sample_position(g) for g in idx]                            # utilities.py:78
+            sl = slice(rank * len(idx) // world, (rank + 1) * len(idx) // world)
+            batch = replay_buffer.sample_batch(config.num_unroll_steps, idx[sl], pos[sl])
+        else:
+            batch = replay_buffer.sample_batch(config.num_unroll_steps)
         losses.append(update_weights(optimizer, network, batch, bucket, group))
         if i % config.checkpoint_interval == 0:
             state_dict = network.state_dict()

@@ -2,6 +2,7 @@
 """Generate the committed golden fixtures by IMPORTING the reference (this container only).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk [n_games]    (verdict only, ~25 min on 8 cores)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -47,14 +48,9 @@ SEED = 1261
 # env traces
 # ------------------------------------------------------------------------------------------------
 def env_state(env):
-    white = black = 0
-    for r in range(8):
-        for c in range(8):
-            v = int(env.board[r, c])
-            if v == 1:
-                white |= 1 << (r * 8 + c)
-            elif v == -1:
-                black |= 1 << (r * 8 + c)
+    cells = env.board.reshape(-1)
+    white = int(np.packbits(cells == 1, bitorder="little").view(np.uint64)[0])    # bit i <=> cell (i // 8, i % 8)
+    black = int(np.packbits(cells == -1, bitorder="little").view(np.uint64)[0])
     legal = 0
     pas = 0
     for a in env.legal_actions:
@@ -652,8 +648,74 @@ def gen_arena():
     np.savez_compressed(os.path.join(HERE, "arena.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# bulk verdict: >= 100k reference games against the oracle's digests, verdict only
+# ------------------------------------------------------------------------------------------------
+def _bulk_chunk(args):
+    """one chunk of reference games -> (digests, action log, final done flags), nothing else kept"""
+    g0, n, seed, vol = args
+    dig = np.zeros(n, np.uint64)
+    acts = np.zeros((n, 60), np.uint8)
+    done = np.zeros(n, np.uint8)
+    last = np.zeros(n, np.int8)
+    for i in range(n):
+        _, rec, actions, rewards, h = play_random_game((g0 + i, seed, vol, 60))
+        dig[i], acts[i], done[i], last[i] = h, actions, rec[-1][4], rewards[-1]
+    return g0, seed, vol, dig, acts, done, last
+
+
+def gen_bulk(n_games=131072):
+    """Every game is played by the imported reference (reversi.py Environment.step) under the build's counter RNG and
+    folded into the 64-bit digest of all 61 states (every field: boards, to_play, steps, done, reward, legal set, pass
+    flag); the oracle (oracle/mz_oracle.c) plays the same game ids and the digests, action logs, done flags and last
+    rewards are compared in-process.  Only the verdict is written: tests/golden/bulk_env_verdict.json."""
+    import json
+    import multiprocessing as mp
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))   # repo root: the oracle package
+    from oracle import mz_oracle as O
+    t0 = time.time()
+    game0 = 1 << 20                      # ids disjoint from the committed fixtures (games 0..4095)
+    n_vol = n_games // 8                 # an eighth of the games also pass voluntarily (reversi.py:135-139)
+    n_reg = n_games - n_vol
+    chunk = 256
+    jobs = [(game0 + g, min(chunk, n_reg - g), SEED, 0) for g in range(0, n_reg, chunk)]
+    jobs += [(game0 + g, min(chunk, n_vol - g), SEED + 1, 1) for g in range(0, n_vol, chunk)]
+    stats = dict(games=0, steps=0, mismatched_digests=0, mismatched_actions=0, mismatched_done=0, mismatched_last_reward=0,
+                 games_with_pass=0, games_with_2plus_passes=0, pass_as_60th_step_done_stays_0=0, not_done_at_end=0,
+                 voluntary_pass_games=0)
+    with mp.Pool(8) as pool:
+        for k, (g0, seed, v, dig, acts, done, last) in enumerate(pool.imap_unordered(_bulk_chunk, jobs)):
+            e, odig, oacts, olast = O.random_playout(seed, g0, len(dig), 60, v, want_actions=True)
+            stats["games"] += len(dig)
+            stats["steps"] += 60 * len(dig)
+            stats["mismatched_digests"] += int((odig != dig).sum())
+            stats["mismatched_actions"] += int((oacts != acts).any(1).sum())
+            stats["mismatched_done"] += int((e.done != done).sum())
+            stats["mismatched_last_reward"] += int((olast != last).sum())
+            npass = (acts == 64).sum(1)
+            stats["games_with_pass"] += int((npass > 0).sum())
+            stats["games_with_2plus_passes"] += int((npass > 1).sum())
+            stats["pass_as_60th_step_done_stays_0"] += int(((acts[:, 59] == 64) & (done == 0)).sum())
+            stats["not_done_at_end"] += int((done == 0).sum())
+            stats["voluntary_pass_games"] += len(dig) if v else 0
+            if k % 32 == 0:
+                print("bulk: %d games, %.0f s, mismatches so far %d" % (stats["games"], time.time() - t0,
+                      stats["mismatched_digests"] + stats["mismatched_actions"]), flush=True)
+    stats.update(first_game_id=game0, seed=SEED, seconds=round(time.time() - t0, 1), processes=8,
+                 reference="/root/reference/reversi.py Environment.step imported in the build container",
+                 compared="64-bit digest of all 61 states per game + action log + final done + last reward vs oracle/mz_oracle.c")
+    with open(os.path.join(HERE, "bulk_env_verdict.json"), "w") as f:
+        json.dump(stats, f, indent=1)
+    print(json.dumps(stats))
+    assert stats["mismatched_digests"] == stats["mismatched_actions"] == stats["mismatched_done"] == 0
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "bulk":
+        gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
     if what in ("env", "all"):
         gen_env()
     if what in ("mcts", "all"):

@@ -166,3 +166,26 @@ def test_run_mcts_and_select_action_vs_fixture(C, golden_dir):
         game = C.Game()
         game.store_search_statistics(root)
         assert (np.array(game.child_visits[0]) == fx["child_visits"][i]).all()
+
+
+def test_noise_follows_the_callers_action_order(C):
+    """add_exploration_noise (main.py:191-196) hands the i-th Dirichlet draw to the i-th action of the list expand_node
+    received -- the reference's root.children order, which is Python-set order there (reversi.py:121-123)"""
+    net = HashNetwork("hash")
+    game = C.Game()
+    out0 = net.initial_inference(torch.from_numpy(game.make_image(0)))
+    order = [44, 19, 37, 26]                       # an unsorted legal list of the opening position
+    priors = {}
+    for acts in (order, sorted(order)):
+        root = C.Node(0, game.to_play())
+        C.expand_node(root, [C.Action(a, game.to_play()) for a in acts], out0)
+        clean = {a: ch.prior for a, ch in root.children.items()}
+        np.random.seed(5)
+        C.add_exploration_noise(root)
+        np.random.seed(5)
+        drawn = np.random.dirichlet([C.config.root_dirichlet_alpha] * 4)
+        frac = C.config.root_exploration_fraction
+        for k, a in enumerate(acts):
+            assert root.children[a].prior == clean[a] * (1 - frac) + drawn[k] * frac, (acts, a)
+        priors[tuple(acts)] = [root.children[a].prior for a in sorted(order)]
+    assert priors[tuple(order)] != priors[tuple(sorted(order))]

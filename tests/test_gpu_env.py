@@ -81,15 +81,31 @@ def test_fused_playout_vs_reference_fixture(menv, env_fx, prefix, seed, vol, n):
     assert (last_reward.cpu().numpy() == env_fx[prefix + "rewards_last"]).all()
 
 
-def test_playout_vs_oracle_262144_games(menv):
-    """a quarter million fresh games (seed/offset not in any fixture): digests of all 61 states"""
-    n, seed, g0 = 262144, 987654321, 5_000_000
+def oracle_playout_threads(seed, g0, n, vol=0, threads=16):
+    """the oracle's playout over n games, split over host threads (ctypes releases the GIL)"""
+    from concurrent.futures import ThreadPoolExecutor
+    chunk = (n + threads - 1) // threads
+    parts = [(g, min(chunk, n - g)) for g in range(0, n, chunk)]
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(lambda p: (p, O.random_playout(seed, g0 + p[0], p[1], 60, vol)), parts))
+
+
+@pytest.mark.parametrize("vol", [0, 1])
+def test_playout_vs_oracle_1M_games(menv, vol):
+    """BASELINE configs[1] at full size against the ORACLE: 1,048,576 fresh games (seed/offset not in any fixture),
+    digests of all 61 states of every game, last rewards and every field of the final states"""
+    n, seed, g0 = 1 << 20, 987654321 + vol, 5_000_000
     e = menv.BatchedEnv(n)
-    digest, _, last_reward = e.random_playout(seed, g0, 60, 0, want_digest=True)
-    o, odig, _, orw = O.random_playout(seed, g0, n, 60, 0)
-    assert (host_u64(digest) == odig).all()
-    assert (last_reward.cpu().numpy() == orw).all()
-    assert_state(e, o)
+    digest, _, last_reward = e.random_playout(seed, g0, 60, vol, want_digest=True)
+    digest, last_reward = host_u64(digest), last_reward.cpu().numpy()
+    st = {k: getattr(e, k).cpu().numpy() for k in ("black", "white", "legal", "to_play", "steps", "done")}
+    for (a, m), (o, odig, _, orw) in oracle_playout_threads(seed, g0, n, vol):
+        sl = slice(a, a + m)
+        assert (digest[sl] == odig).all() and (last_reward[sl] == orw).all()
+        for k in ("black", "white", "legal"):
+            assert (st[k][sl].view(np.uint64) == getattr(o, k)).all(), k
+        for k in ("to_play", "steps", "done"):
+            assert (st[k][sl] == getattr(o, k)).all(), k
 
 
 def test_step_kernel_path_equals_fused_path_1M(menv):
