@@ -332,6 +332,27 @@ typedef struct mz_heads_weights {
 int mz_inference_forward(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, void *hidden,
                          int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One whole search per call: the per-move body of play_game (main.py:75-87) for n_trees games with the
+ * HIP inference launch as the network -- initial_inference(image) (network.py:146-153), expand_node over
+ * the legal moves + add_exploration_noise (main.py:82-83), n_sims x [select_child descent, recurrent_inference
+ * (network.py:155-163), expand_node, backpropagate] (run_mcts, main.py:99-125), then the root statistics
+ * store_search_statistics / select_action consume.  Exactly the launches a caller would make through
+ * mz_inference_forward / mz_mcts_root_init / mz_mcts_select / mz_mcts_backup_select / mz_mcts_root_stats,
+ * issued from C (no per-launch host-language overhead).
+ *   repr / dyn : prepacked Representation (cin 9) and Dynamics (cin 10) towers; heads: prediction heads
+ *   image      : (n,9,8,8) bf16 NCHW (mz_make_image with MZ_BF16); noise: (n,65) f64 by action, nullable
+ *   workspace  : caller-owned device scratch of >= mz_search_workspace_bytes(n_trees, n_sims) bytes, 256-B
+ *                aligned: the node pool (bf16 hidden states) and the staging rows between the tree kernels
+ *                and the inference launch; contents need not be preserved between calls
+ *   visits     : (n,65) i32, -1 = not a root child; root_value: (n) f32
+ * Performs mz_pool_init's one small synchronous upload of the pb_c table. */
+int64_t mz_search_workspace_bytes(int32_t n_trees, int32_t n_sims);   /* -1 on bad arguments */
+int mz_search(const mz_tower_weights *repr, const mz_tower_weights *dyn, const mz_heads_weights *heads,
+              const mz_search_cfg *cfg, const void *image, const int8_t *to_play, const uint64_t *legal,
+              const double *noise, int32_t n_sims, int32_t n_trees, void *workspace, int64_t workspace_bytes,
+              int32_t *visits, float *root_value, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

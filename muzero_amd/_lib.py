@@ -88,6 +88,8 @@ SIGNATURES = {
     "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
     "mz_tower_forward": [C.POINTER(TowerWeights), _p, _p, _i32, _i64, _p],
     "mz_inference_forward": [C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _p, _p, _i32, _p, _p, _i64, _p],
+    "mz_search": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32, _p, _i64,
+                  _p, _p, _p],
     "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }
@@ -95,11 +97,13 @@ for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)
     _f.argtypes = _args
     _f.restype = C.c_int
+lib.mz_search_workspace_bytes.restype = C.c_int64
+lib.mz_search_workspace_bytes.argtypes = [_i32, _i32]
 lib.mz_last_error.restype = C.c_char_p
 lib.mz_last_error.argtypes = []
 lib.mz_version.restype = C.c_int
 lib.mz_version.argtypes = []
-EXPORTS = sorted(list(SIGNATURES) + ["mz_last_error", "mz_version"])
+EXPORTS = sorted(list(SIGNATURES) + ["mz_last_error", "mz_version", "mz_search_workspace_bytes"])
 
 
 def call(name, *args):

@@ -117,6 +117,44 @@ class BatchedMCTS:
             raise L.MzError("value must be float32 with n elements")
 
 
+class FusedSearch:
+    """mz_search -- the whole per-move search of play_game (main.py:75-87) for n trees in ONE C call: initial inference,
+    root expansion + noise, S x (recurrent inference + fused tree kernel), root statistics.  Needs an InferenceEngine
+    serving through the HIP tower (bf16); the node pool and staging rows live in `workspace` (device scratch)."""
+
+    def __init__(self, engine, n_trees, n_sims, device="cuda", cfg=None):
+        if getattr(engine, "tower", None) != "hip":
+            raise L.MzError("FusedSearch needs an InferenceEngine with tower='hip' (bf16)")
+        self.engine, self.n, self.S = engine, int(n_trees), int(n_sims)
+        self.device = torch.device(device)
+        self.cfg = search_cfg(cfg)
+        nbytes = L.lib.mz_search_workspace_bytes(self.n, self.S)
+        if nbytes < 0:
+            raise L.MzError("mz_search_workspace_bytes(%d, %d) rejected its arguments" % (self.n, self.S))
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def _weights(self):
+        pk = self.engine._packs
+        return C.byref(pk["repr"]["struct"]), C.byref(pk["dyn"]["struct"]), C.byref(pk["heads"]["struct"])
+
+    def _io(self, image, to_play, legal, n):
+        if image.dtype != torch.bfloat16 or tuple(image.shape) != (n, 9, 8, 8):
+            raise L.MzError("image must be a bf16 (n,9,8,8) tensor")
+        if to_play.dtype != torch.int8 or legal.dtype != torch.int64 or to_play.numel() != n or legal.numel() != n:
+            raise L.MzError("to_play must be int8 (n,), legal int64 (n,)")
+        visits = torch.empty((n, 65), dtype=torch.int32, device=self.device)
+        root_value = torch.empty(n, dtype=torch.float32, device=self.device)
+        return visits, root_value
+
+    def __call__(self, image, to_play, legal, noise=None, n_trees=None, n_sims=None):
+        n = self.n if n_trees is None else int(n_trees)
+        S = self.S if n_sims is None else int(n_sims)
+        visits, root_value = self._io(image, to_play, legal, n)
+        L.call("mz_search", *self._weights(), C.byref(self.cfg), L.dptr(image), L.dptr(to_play), L.dptr(legal), L.dptr(noise), S, n,
+               L.dptr(self.workspace), self.workspace.numel(), L.dptr(visits), L.dptr(root_value), L.current_stream())
+        return visits, root_value
+
+
 def select_action(visits, num_moves, u):
     """select_action + softmax_sample (main.py:128-140, 275-285) for n searches.
     visits int32 (n,65) (-1 = not a child); num_moves int or int32 (n,); u float64 (n,) uniforms."""

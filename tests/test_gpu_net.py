@@ -44,9 +44,11 @@ def test_fused_engine_matches_module_forward(dtype, tol):
             assert u.shape == v.shape and u.dtype == v.dtype
             assert (u.float() - v.float()).abs().max().item() <= tol * max(1.0, v.float().abs().max().item()), name
     # and against the reference-API forward of the fp32 module
+    # the engines serve deep copies: the caller's module keeps its device, dtype and trainability
+    assert all(p.device.type == "cpu" and p.dtype == torch.float32 and p.requires_grad for p in net.parameters())
     if dtype == torch.float32:
         with torch.no_grad():
-            v, p, h = net.recurrent_inference(x10[:, :8], x10[:, 8:])
+            v, p, h = net.cuda().recurrent_inference(x10[:, :8], x10[:, 8:])
         a = fused.recurrent(x10)
         assert (a[0] - v.reshape(-1)).abs().max().item() < 1e-5 and (a[1] - p).abs().max().item() < 1e-5
 
@@ -77,7 +79,7 @@ def test_hip_tower_vs_torch_fp32_reference(n):
                 p.uniform_(-0.3, 0.3)
     eng = InferenceEngine(net, n, torch.bfloat16, tower="hip")
     ref = Network().cuda()
-    ref.load_state_dict(net.state_dict())
+    ref.load_state_dict({k: v.to(torch.bfloat16).float() for k, v in net.state_dict().items()})   # the served (bf16-rounded) weights
     gen = torch.Generator(device="cuda").manual_seed(n)
     img = (torch.rand(n, 9, 8, 8, device="cuda", generator=gen) < 0.3).to(torch.bfloat16)
     x10 = torch.rand(n, 10, 8, 8, device="cuda", generator=gen).to(torch.bfloat16)

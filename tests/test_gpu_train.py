@@ -17,7 +17,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4       # |sum_gpu - sum_ref| <= TOL * abs-sum_ref (measured on MI355X: see the assertion message when it fails)
+TOL = 2e-3       # |sum_gpu - sum_ref| <= TOL * abs-sum_ref.  Measured on MI355X: up to 5.4e-4 by the third step (MIOpen's fp32
+                 # convolution algorithms are not the CPU's direct sums, and after two updates a few ReLU gates of the 4-sample
+                 # batch sit on the other side of zero); the CPU run of the same code meets 2e-5 (tests/test_train.py)
+ELEM_TOL = 1e-2  # every gradient ELEMENT against the CPU run of the same step from the same weights, relative to the tensor's max
 LOSS_TOL = 2e-4  # the reference prints 4 decimals
 
 
@@ -66,13 +69,28 @@ def test_update_weights_on_gpu_matches_reference(golden_dir, flat):
             seen = {}
             orig = opt.step
 
+            seen_grads = {}
+
             def rec(*a, **k):
                 seen["g"] = _sums([p.grad for p in params])
+                seen_grads.update({k_: p.grad.detach().clone() for k_, p in net.named_parameters()})
                 return orig(*a, **k)
 
             opt.step = rec
+            # CPU twin of this very step: same weights, same batch, the code path tests/test_train.py pins on the reference
+            twin = Network()
+            twin.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+            twin.train()
+            pl, vl = T.muzero_loss(twin, tuple(t.cpu() for t in batch))
+            (pl + vl).backward()
             p_loss, v_loss = T.update_weights(opt, net, batch, bucket)
             opt.step = orig
+            assert abs(float(pl) - float(p_loss)) <= 1e-4 and abs(float(vl) - float(v_loss)) <= 1e-4
+            worst = 0.0
+            for (k, a), b in zip(net.named_parameters(), twin.parameters()):
+                ga, gb = seen_grads[k].cpu(), b.grad
+                worst = max(worst, float((ga - gb).abs().max() / gb.abs().max().clamp_min(1e-12)))
+            assert worst <= ELEM_TOL, "step %d: worst gradient element error %.3g of the tensor's max" % (step, worst)
             _check(seen["g"], G["train_grad_sums"][step], "gradients of step %d" % step)
             _check(_sums([p.detach() for p in params]), G["train_weight_sums"][step], "weights after step %d" % step)
             ref = str(G["train_logs"][step]).split()          # 'step 0: p_loss 4.1744 v_loss 4.4605'
