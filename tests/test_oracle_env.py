@@ -93,3 +93,13 @@ def test_features(golden_dir):
         got = O.make_image(fx["hist_white"][g], fx["hist_black"][g], int(idx))
         assert (got == img.astype(np.float32)).all(), (g, idx)
     assert O.make_image(fx["hist_white"][0], fx["hist_black"][0], 0).sum() == 64  # only the turn plane
+
+
+def test_bulk_reference_verdict_is_committed_and_clean(golden_dir):
+    """>= 100k games played by the IMPORTED reference (tests/golden/make_golden.py bulk, build container only)
+    against this oracle's digests of all 61 states; only the verdict travels."""
+    import json
+    v = json.load(open(os.path.join(golden_dir, "bulk_env_verdict.json")))
+    assert v["games"] >= 100_000 and v["steps"] == 60 * v["games"]
+    assert v["mismatched_digests"] == v["mismatched_actions"] == v["mismatched_done"] == v["mismatched_last_reward"] == 0
+    assert v["games_with_2plus_passes"] > 1000 and v["pass_as_60th_step_done_stays_0"] > 1000 and v["voluntary_pass_games"] > 1000
