@@ -353,6 +353,25 @@ int mz_search(const mz_tower_weights *repr, const mz_tower_weights *dyn, const m
               const double *noise, int32_t n_sims, int32_t n_trees, void *workspace, int64_t workspace_bytes,
               int32_t *visits, float *root_value, void *stream);
 
+/* mz_search for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE (which has no native boundary at all):
+ * it exists for code under hipGraph capture, tight serving loops and harnesses that forbid hipMalloc.  Same inputs,
+ * outputs and results as mz_search (bit-identical visits and root values), but the workspace is a file-scope device array
+ * of MZ_SEARCH_NOALLOC_BYTES inside the library -- every GPU the library runs on holds its own copy until the process
+ * ends -- and the call performs no hipMalloc / hipFree / allocating library routine.
+ *   limits : mz_search_workspace_bytes(n_trees, n_sims) + 64 KiB <= MZ_SEARCH_NOALLOC_BYTES (e.g. 128 trees x 50
+ *            simulations, 64 x 100, 1 x 4095) and n_sims <= MZ_SEARCH_NOALLOC_MAX_SIMS; larger requests are refused with
+ *            MZ_E_ARG and a message naming mz_search;
+ *   state  : the array keeps the last call's contents; the call rewrites everything it reads.  All calls on one GPU
+ *            share that GPU's array: calls that overlap in time on one GPU (two streams, two threads) RACE -- serialise them;
+ *   first call on a device, and any call that changes cfg->pb_c_base / pb_c_init, uploads the pb_c table with one small
+ *            synchronous copy: make that call before starting a graph capture. */
+#define MZ_SEARCH_NOALLOC_BYTES (16 << 20)
+#define MZ_SEARCH_NOALLOC_MAX_SIMS 4095
+int mz_search_noalloc(const mz_tower_weights *repr, const mz_tower_weights *dyn, const mz_heads_weights *heads,
+                      const mz_search_cfg *cfg, const void *image, const int8_t *to_play, const uint64_t *legal,
+                      const double *noise, int32_t n_sims, int32_t n_trees, int32_t *visits, float *root_value,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

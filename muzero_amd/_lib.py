@@ -90,6 +90,8 @@ SIGNATURES = {
     "mz_inference_forward": [C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _p, _p, _i32, _p, _p, _i64, _p],
     "mz_search": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32, _p, _i64,
                   _p, _p, _p],
+    "mz_search_noalloc": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32,
+                          _p, _p, _p],
     "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }

@@ -122,7 +122,9 @@ class FusedSearch:
     root expansion + noise, S x (recurrent inference + fused tree kernel), root statistics.  Needs an InferenceEngine
     serving through the HIP tower (bf16); the node pool and staging rows live in `workspace` (device scratch)."""
 
-    def __init__(self, engine, n_trees, n_sims, device="cuda", cfg=None):
+    def __init__(self, engine, n_trees, n_sims, device="cuda", cfg=None, noalloc=False):
+        """noalloc=True: no workspace tensor; calls go to mz_search_noalloc, whose scratch is a static device array inside
+        the library (limits in include/muzero_amd.h; calls that overlap on one GPU race)"""
         if getattr(engine, "tower", None) != "hip":
             raise L.MzError("FusedSearch needs an InferenceEngine with tower='hip' (bf16)")
         self.engine, self.n, self.S = engine, int(n_trees), int(n_sims)
@@ -131,7 +133,7 @@ class FusedSearch:
         nbytes = L.lib.mz_search_workspace_bytes(self.n, self.S)
         if nbytes < 0:
             raise L.MzError("mz_search_workspace_bytes(%d, %d) rejected its arguments" % (self.n, self.S))
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.workspace = None if noalloc else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _weights(self):
         pk = self.engine._packs
@@ -150,6 +152,10 @@ class FusedSearch:
         n = self.n if n_trees is None else int(n_trees)
         S = self.S if n_sims is None else int(n_sims)
         visits, root_value = self._io(image, to_play, legal, n)
+        if self.workspace is None:
+            L.call("mz_search_noalloc", *self._weights(), C.byref(self.cfg), L.dptr(image), L.dptr(to_play), L.dptr(legal), L.dptr(noise),
+                   S, n, L.dptr(visits), L.dptr(root_value), L.current_stream())
+            return visits, root_value
         L.call("mz_search", *self._weights(), C.byref(self.cfg), L.dptr(image), L.dptr(to_play), L.dptr(legal), L.dptr(noise), S, n,
                L.dptr(self.workspace), self.workspace.numel(), L.dptr(visits), L.dptr(root_value), L.current_stream())
         return visits, root_value
