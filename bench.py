@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tower", default="auto", choices=["auto", "hip", "miopen"], help="inference path (auto = hip for bf16)")
     ap.add_argument("--env-games", type=int, default=1 << 20)
+    ap.add_argument("--env-games-hbm", type=int, default=1 << 24, help="second env point whose state exceeds the caches (0 = skip)")
+    ap.add_argument("--fp32-steps", type=int, default=2, help="searches of the fp32-inference companion leg (0 = skip)")
     ap.add_argument("--selfplay-games", type=int, default=4096)
     ap.add_argument("--selfplay-sims", type=int, default=50)
     ap.add_argument("--skip-extras", action="store_true", help="only the timed MCTS leg")
@@ -88,8 +90,8 @@ def make_roots(n, seed, game0, device):
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md): FETCH_SIZE
     (doubled, MI355X_MICROARCH.md gfx950 correction) + WRITE_SIZE at this bench's launch shape.
-    rocprofv3 cannot run inside this process, so the number is read from the newest profile; None
-    when no profile is present."""
+    rocprofv3 cannot run inside this process, so the number is read from the newest committed profile of this
+    same command (profiles/rNN/pmc_summary.json, regenerated every round); None when no profile is present."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -111,7 +113,11 @@ def event_time_ms(fn, iters):
     return start.elapsed_time(end) / iters
 
 
-ENV_VALU_INSTR, ENV_VALU_CYCLES = 373, 1072
+def kernel_isa(kernel):
+    """static VALU census of the kernel's gfx950 ISA, generated from the CURRENT sources by __graft_entry__.build()
+    (tools/isa_stats.py -> muzero_amd/lib/kernel_isa.json); None when the file is absent (never a literal)"""
+    f = os.path.join(ROOT, "muzero_amd", "lib", "kernel_isa.json")
+    return json.load(open(f)).get(kernel) if os.path.exists(f) else None
 
 
 def bench_env(args, device):
@@ -121,40 +127,61 @@ def bench_env(args, device):
     e.random_playout(1261, 0, 60, 0)
     torch.cuda.synchronize()
     ms_fused = event_time_ms(lambda: e.random_playout(1261, 0, 60, 0), 5)
-    # HBM-resident path: one k_env_step launch per step over states in HBM (actions precomputed)
-    e.reset()
-    acts = torch.empty((60, n), dtype=torch.uint8, device=device)
-    for t in range(60):
-        e.random_action(1261, 0, t, out=acts[t])
-        e.step(acts[t])
-    torch.cuda.synchronize()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tot = 0.0
-    reps = 3
-    for _ in range(reps):
+
+    def step_kernel_ms(e, n, game0, reps):
+        """HBM-resident path: one k_env_step launch per step over states in HBM (actions precomputed)"""
         e.reset()
-        start.record()
+        acts = torch.empty((60, n), dtype=torch.uint8, device=device)
         for t in range(60):
+            e.random_action(1261, game0, t, out=acts[t])
             e.step(acts[t])
-        end.record()
-        end.synchronize()
-        tot += start.elapsed_time(end)
-    ms_step = tot / (reps * 60)
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            e.reset()
+            start.record()
+            for t in range(60):
+                e.step(acts[t])
+            end.record()
+            end.synchronize()
+            tot += start.elapsed_time(end)
+        return tot / (reps * 60)
+
+    ms_step = step_kernel_ms(e, n, 0, 3)
     gbps = n * ENV_BYTES_PER_STEP / (ms_step * 1e-3) / 1e9
+    del e
+    # the same kernel on a state that cannot sit in the caches: 16 M games = 336 MB of state arrays + 16 MB of actions per
+    # step against 256 MB of Infinity Cache + 32 MB of L2, so THIS fraction is an HBM fraction
+    big = args.env_games_hbm
+    roof_big = None
+    if big > 0:
+        eb = BatchedEnv(big, device)
+        ms_big = step_kernel_ms(eb, big, 1 << 24, 1)
+        g2 = big * ENV_BYTES_PER_STEP / (ms_big * 1e-3) / 1e9
+        roof_big = {"kernel": "k_env_step", "games": big, "bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": g2 / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": ms_big * 1e3, "env_steps_per_sec": big / (ms_big * 1e-3),
+                    "working_set_bytes": big * 21, "note": "state exceeds L2 + Infinity Cache: served from HBM"}
+        del eb
+    isa = kernel_isa("k_env_step")
+    valu = None
+    if isa:   # SURVEY 8(d): the env's floor is its integer ALU work, so the VALU issue rate is reported beside the GB/s
+        waves = n / 64
+        valu = {"instructions_per_wave_step": isa["valu_instructions"], "half_rate_64bit_shifts": isa["half_rate_64bit_shifts"],
+                "issue_cycles_per_wave_step": isa["issue_cycles_per_wave"], "source": "muzero_amd/lib/kernel_isa.json (build-time census of the gfx950 ISA)",
+                "wave_instructions_per_sec": waves * isa["valu_instructions"] / (ms_step * 1e-3),
+                "busy_frac_at_2.4GHz": waves * isa["issue_cycles_per_wave"] / 1024 / 2.4e9 / (ms_step * 1e-3)}
     return {
         "env_games": n,
         "env_steps_per_sec_fused_playout": n * 60 / (ms_fused * 1e-3),
         "env_steps_per_sec_step_kernel": n / (ms_step * 1e-3),
         "roofline_env": {"kernel": "k_env_step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step"), "bytes_per_step": ENV_BYTES_PER_STEP,
-                         "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP,
-                         "us_per_launch": ms_step * 1e3,
-                         # the env's floor is its integer ALU work, so the VALU rate is reported beside the GB/s.
-                         # Static count from the gfx950 ISA of k_env_step: 373 VALU instructions per wave-step, 98 of them
-                         # half-rate 64-bit shifts -> ~1070 issue cycles per wave (measured rates: 2.4 / 4.2 cycles, env_kernels.hip)
-                         "valu": {"instructions_per_wave_step": ENV_VALU_INSTR, "issue_cycles_per_wave_step": ENV_VALU_CYCLES,
-                                  "wave_instructions_per_sec": n / 64 * ENV_VALU_INSTR / (ms_step * 1e-3),
-                                  "busy_frac_at_2.4GHz": n / 64 * ENV_VALU_CYCLES / 1024 / 2.4e9 / (ms_step * 1e-3)}},
+                         "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP, "us_per_launch": ms_step * 1e3,
+                         "note": "nominal: the 1,048,576-game state (22 MB + actions) stays resident in L2 + Infinity Cache, so this is "
+                                 "algorithmic bytes over time, not HBM traffic; the kernel is VALU-issue bound (valu) -- roofline_env_hbm is the HBM point",
+                         "valu": valu},
+        "roofline_env_hbm": roof_big,
     }
 
 
@@ -225,47 +252,48 @@ def bench_loop(args, device, dtype):
             "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 
 
-def bench_cpu_baseline(args):
-    """C oracle tree search + PyTorch CPU inference on the host cores (bounded sample)."""
+def bench_cpu_baseline(args, roots, image, noise):
+    """The CPU port on the SAME roots as the GPU leg: C oracle tree search (one call per simulation over all trees, OpenMP)
+    + PyTorch CPU fp32 inference on the host cores; a bounded sample (one search of every tree)."""
     import numpy as np
     from oracle import mz_oracle as O
     from muzero_amd.network import Network
     threads = max(1, min(16, os.cpu_count() or 1))
     torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     torch.manual_seed(1261)
     net = Network().eval()
-    n, S = args.cpu_trees, args.sims
-    trees = [O.Tree(S) for _ in range(n)]
-    legal = sum(1 << i for i in (19, 26, 44, 37))
-    img = torch.zeros(n, 9, 8, 8)
-    img[:, 8] = 1
-    rng = np.random.default_rng(0)
+    n, S = min(args.cpu_trees, roots.n), args.sims
+    to_play = roots.to_play[:n].cpu().numpy()
+    legal = roots.legal[:n].cpu().numpy().view(np.uint64)
+    img = image[:n].float().cpu()
+    nz = noise[:n].cpu().numpy()
+    tb = O.TreeBatch(n, S)
+    pool = np.zeros((S + 1, n, 512), np.float32)
+    x = np.zeros((n, 10, 8, 8), np.float32)
+    xt = torch.from_numpy(x)
     t0 = time.perf_counter()
     with torch.no_grad():
         v, p, h = net.initial_inference(img)
-        hid = {0: h}
-        pn = p.numpy()
-        for g, t in enumerate(trees):
-            noise = np.zeros(65)
-            noise[[19, 26, 44, 37]] = rng.dirichlet([0.03] * 4)
-            t.root_init(-1, legal, 0, pn[g], noise)
-        pool = torch.zeros(S + 1, n, 8, 8, 8)
-        pool[0] = h
-        x = torch.zeros(n, 10, 8, 8)
+        pool[0] = h.reshape(n, 512).numpy()
+        tb.root_init(to_play, legal, p.numpy(), nz)
         for s in range(S):
-            for g, t in enumerate(trees):
-                d, pid, a, plane, _ = t.select()
-                x[g, :8] = pool[pid, g]
-                x[g, 8:] = torch.from_numpy(O.action_encode(a, 1 if plane == 0 else -1).astype(np.float32))
-            v, p, h = net.recurrent_inference_packed(x)
-            pool[s + 1] = h
-            vn, pn = v.numpy().reshape(-1), p.numpy()
-            for g, t in enumerate(trees):
-                t.expand_backup(vn[g], pn[g])
+            tb.select(pool, x)
+            v, p, h = net.recurrent_inference_packed(xt)
+            pool[s + 1] = h.reshape(n, 512).numpy()
+            tb.expand_backup(v.numpy().reshape(-1), p.numpy())
     dt = time.perf_counter() - t0
-    return {"value": n * S / dt, "unit": "simulations/s", "cores": threads, "kind": "port",
-            "sample": "%d trees x %d sims from the opening: C oracle (oracle/mz_oracle.c) tree search + PyTorch CPU fp32 "
-                      "inference, batch %d, %.1f s" % (n, S, n, dt)}
+    out = {"value": n * S / dt, "unit": "simulations/s", "cores": threads, "kind": "port",
+           "sample": "one search of %d trees x %d sims on the GPU leg's roots (positions after 0..59 moves, same noise): C oracle "
+                     "(oracle/mz_oracle.c, one OpenMP call per simulation) + PyTorch CPU fp32 inference at batch %d, %.1f s" % (n, S, n, dt)}
+    # SURVEY 8(d) (i)/(ii): the reference cannot run on the GPU box; its ratio to this port was measured with both on the
+    # build container's 8 cores (tools/cpu_ratio.py -> profiles/r02/cpu_ratio_container.json)
+    f = os.path.join(ROOT, "profiles", "r02", "cpu_ratio_container.json")
+    if os.path.exists(f):
+        r = json.load(open(f))
+        out["ratio_to_reference"] = r["port_sims_per_sec"] / r["reference_sims_per_sec"]
+        out["reference_container"] = {k: r[k] for k in ("reference_sims_per_sec", "port_sims_per_sec", "cores", "workload")}
+    return out, tb.root_visits()
 
 
 def main():
@@ -325,7 +353,10 @@ def main():
     out = {
         "metric": "mcts_simulations_per_sec", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        # the arithmetic the path computes in: the tree is the reference's (double priors / pb_c, fp32 value sums); the network
+        # inference that feeds it runs in args.dtype (the reference's network is fp32: see "fp32_inference" and "bf16_vs_fp32_search")
+        "dtype": "f64/f32 tree + %s inference" % args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %d game trees per GPU x %d simulations per search; random-init MuZero net "
                                "(seed 1261), %s inference on the whole leaf batch once per simulation (%s); roots = positions after "
                                "0..59 random moves; tree arithmetic f64/f32 as the reference" %
@@ -408,7 +439,43 @@ def main():
                 out["train"] = bench_train(args, device, rec)
                 del sp, net_sp, rec
                 out["loop"] = bench_loop(args, device, dtype)
-        out["cpu_baseline"] = bench_cpu_baseline(args)
+        # ---- reference-precision companion (network.py:146-163 is fp32): the same searches with fp32 inference through
+        # PyTorch-ROCm/MIOpen and an fp32 hidden-state pool, and what bf16 serving does to the search's OUTPUT
+        bf16_visits, _ = eng.search(image, noise)
+        bf16_visits = bf16_visits.clone()
+        del eng
+        if args.fp32_steps > 0 and dtype != torch.float32:
+            from muzero_amd.metrics import visit_agreement
+            torch.manual_seed(1261)
+            net32 = InferenceEngine(Network(), n, torch.float32, tower="miopen")
+            eng32 = SelfPlayEngine(n, net32, num_simulations=S, device=device, use_graph=not args.no_graph, seed=1261 + rank)
+            eng32.env = roots
+            image32 = image.float()
+            fp32_visits, _ = eng32.search(image32, noise)   # warm-up + the agreement sample (same roots, same noise)
+            fp32_visits = fp32_visits.clone()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.fp32_steps):
+                eng32.search(image32, noise)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / args.fp32_steps
+            ms32 = event_time_ms(lambda: net32.recurrent(eng32.mcts.net_in), 10)
+            tf32 = n * NET_MFLOP * 1e6 / (ms32 * 1e-3) / 1e12
+            out["fp32_inference"] = {"value": n * S / dt32, "unit": "simulations/s", "ms_per_step": dt32 * 1e3, "steps": args.fp32_steps,
+                                     "inference": "PyTorch-ROCm / MIOpen fp32 (+ fused bias/ReLU epilogue), fp32 hidden-state pool",
+                                     "roofline": {"bound": "mfma", "achieved": tf32, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": tf32 / F32_PEAK_TFLOPS, "us_per_launch_sequence": ms32 * 1e3, "traffic": None}}
+            out["bf16_vs_fp32_search"] = dict(visit_agreement(fp32_visits, bf16_visits),
+                                              note="same %d roots, same Dirichlet noise, %d simulations: bf16 HIP tower vs fp32 MIOpen inference" % (n, S))
+            del eng32, net32
+        else:
+            fp32_visits = None
+        cpu, cpu_visits = bench_cpu_baseline(args, roots, image, noise)
+        out["cpu_baseline"] = cpu
+        if fp32_visits is not None:
+            from muzero_amd.metrics import visit_agreement
+            k = cpu_visits.shape[0]
+            out["cpu_baseline"]["search_agreement_with_gpu_fp32"] = visit_agreement(torch.from_numpy(cpu_visits), fp32_visits[:k].cpu())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

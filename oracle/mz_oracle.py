@@ -74,6 +74,10 @@ def lib():
         L.mzo_arena_game_hashnet.restype = C.c_int
         L.mzo_arena_game_hashnet.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, p, C.c_int, p, p, p]
         L.mzo_replay_sample.argtypes = [p] * 5 + [C.c_int] * 3 + [p] * 4
+        L.mzo_root_init_batch.argtypes = [p, C.c_int, p, p, p, p]
+        L.mzo_select_batch.argtypes = [p, C.c_int, p, p, p]
+        L.mzo_expand_backup_batch.argtypes = [p, C.c_int, p, p]
+        L.mzo_root_visits_batch.argtypes = [p, C.c_int, p]
         _lib = L
     return _lib
 
@@ -289,3 +293,35 @@ def arena_game_hashnet(mode_black, mode_white, S, temperature, u, max_steps=60):
     n = lib().mzo_arena_game_hashnet(int(mode_black), int(mode_white), int(S), float(temperature), ptr(u), int(max_steps), ptr(actions),
                                      C.byref(ws), C.byref(bs))
     return n, actions[:n], ws.value, bs.value
+
+
+# ---------------------------------------------------------------------------------------------
+# batch forms (bench.py cpu_baseline): one C call per simulation over all trees, OpenMP inside
+# ---------------------------------------------------------------------------------------------
+class TreeBatch:
+    def __init__(self, n, max_sims, **cfg):
+        self.trees = [Tree(max_sims, **cfg) for _ in range(n)]
+        self.n = n
+        self.handles = (C.c_void_p * n)(*[t.h for t in self.trees])
+
+    def root_init(self, to_play, legal, policy, noise=None):
+        to_play = np.ascontiguousarray(to_play, np.int8)
+        legal = np.ascontiguousarray(legal, np.uint64)
+        policy = np.ascontiguousarray(policy, np.float32)
+        noise = None if noise is None else np.ascontiguousarray(noise, np.float64)
+        lib().mzo_root_init_batch(self.handles, self.n, ptr(to_play), ptr(legal), ptr(policy), ptr(noise))
+
+    def select(self, pool, x, depth=None):
+        """pool: float32 [nodes][n][512] hidden states by expansion serial; x: float32 [n][10][8][8] written in place"""
+        assert pool.dtype == np.float32 and pool.flags.c_contiguous and x.dtype == np.float32 and x.flags.c_contiguous
+        lib().mzo_select_batch(self.handles, self.n, ptr(pool), ptr(x), ptr(depth))
+
+    def expand_backup(self, value, policy):
+        value = np.ascontiguousarray(value, np.float32)
+        policy = np.ascontiguousarray(policy, np.float32)
+        lib().mzo_expand_backup_batch(self.handles, self.n, ptr(value), ptr(policy))
+
+    def root_visits(self):
+        v = np.zeros((self.n, 65), np.int32)
+        lib().mzo_root_visits_batch(self.handles, self.n, ptr(v))
+        return v
