@@ -314,14 +314,15 @@ int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int
 
 /* Prediction heads (network.py:79-111) fused behind the tower: 1x1 conv 8->2 + ReLU + Flatten +
  * Linear(128,128) + ReLU + Linear(128,65) + Softmax (policy); 1x1 conv 8->2 + ReLU + Flatten +
- * Linear(128,1) + Tanh (value).  f32 arithmetic.  The two Linear matrices are bf16 (the serving network's weights are
- * bf16 values: nothing is lost, and the heads read half the bytes), TRANSPOSED and packed in input PAIRS:
- * element [r][out] is one 32-bit word {low half: W[out][2r], high half: W[out][2r+1]}.  Everything else is f32. */
+ * Linear(128,1) + Tanh (value).  The two Linear matrices are bf16 in nn.Linear's own [out][in] layout (the serving
+ * network's weights are bf16 values: nothing is lost) and run on the matrix cores, sixteen boards per pass, with every fp32
+ * input feature split into two bf16 terms (hi + lo: 16 significant bits, exact products, fp32 sums); everything else is f32
+ * arithmetic.  Within 2e-5 of the fp32 module on the same hidden state. */
 typedef struct mz_heads_weights {
     const float *pc_w, *pc_b;   /* policy_head.0: [2][8], [2] */
-    const uint32_t *p1_wt;      /* policy_head.3 weight: bf16 pairs [64 input pairs][128 out] */
+    const void *p1_w;           /* policy_head.3 weight: bf16 [128 out][128 in] */
     const float *p1_b;          /* [128] */
-    const uint32_t *p2_wt;      /* policy_head.5 weight: bf16 pairs [64 input pairs][65 out] */
+    const void *p2_w;           /* policy_head.5 weight: bf16 [65 out][128 in] */
     const float *p2_b;          /* [65] */
     const float *vc_w, *vc_b;   /* value_head.0: [2][8], [2] */
     const float *v1_w, *v1_b;   /* value_head.3: [128], [1] */

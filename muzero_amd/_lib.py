@@ -49,8 +49,8 @@ class TowerWeights(C.Structure):
 
 
 class HeadsWeights(C.Structure):
-    """mz_heads_weights -- device pointers of the prediction heads (f32; p1_wt / p2_wt bf16 input pairs)"""
-    _fields_ = [(k, C.c_void_p) for k in ("pc_w", "pc_b", "p1_wt", "p1_b", "p2_wt", "p2_b", "vc_w", "vc_b", "v1_w", "v1_b")]
+    """mz_heads_weights -- device pointers of the prediction heads (f32; p1_w / p2_w bf16 [out][in])"""
+    _fields_ = [(k, C.c_void_p) for k in ("pc_w", "pc_b", "p1_w", "p1_b", "p2_w", "p2_b", "vc_w", "vc_b", "v1_w", "v1_b")]
 
 
 if not os.path.exists(LIB_PATH):

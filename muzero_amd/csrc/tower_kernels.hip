@@ -34,6 +34,10 @@
 // is a linear copy.
 #include "common.h"
 
+#ifndef MZ_DIAG
+#define MZ_DIAG 0   // diagnostic builds only (tools/build_variant.sh ... -DMZ_DIAG=mask): pieces of the non-K-loop phases are skipped to price them
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -63,13 +67,12 @@ struct Tower {
     long long *stamps;     // diagnostics: [blocks][24] s_memtime stamps at the phase boundaries (null = off)
 };
 
-// prediction heads (network.py:79-111): FC matrices as bf16 input pairs [in / 2][out] (one dword = inputs 2r, 2r + 1 of one
-// output) so lanes (= outputs) read coalesced and a thread's 32 inputs are 16 dwords; everything else f32
+// prediction heads (network.py:79-111): the two Linear matrices in bf16 (the serving network's weights are bf16 values), everything else f32
 struct Heads {
     const float *pc_w, *pc_b;    // policy 1x1 conv [2][8], [2]
-    const uint32_t *p1_wt;       // Linear(128,128) as bf16 pairs [64][out 128]
+    const uint16_t *p1_w;        // Linear(128,128) weight, bf16 [out 128][in 128] (nn.Linear layout)
     const float *p1_b;           // [128]
-    const uint32_t *p2_wt;       // Linear(128,65)  as bf16 pairs [64][out 65]
+    const uint16_t *p2_w;        // Linear(128,65) weight, bf16 [out 65][in 128]
     const float *p2_b;           // [65]
     const float *vc_w, *vc_b;    // value 1x1 conv [2][8], [2]
     const float *v1_w, *v1_b;    // Linear(128,1) [128], [1]
@@ -155,7 +158,7 @@ __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict_
 
 #define MZ_STAMP(tw, k)                                                                              \
     do {                                                                                             \
-        if ((tw).stamps && threadIdx.x == 0) (tw).stamps[(int64_t)blockIdx.x * 24 + (k)] = (long long)__builtin_readcyclecounter(); \
+        if ((tw).stamps && threadIdx.x == 0) (tw).stamps[(k)] = (long long)__builtin_readcyclecounter(); /* stamps: this tile's row */ \
     } while (0)
 
 // MFMA shape of the K loop: v_mfma_f32_16x16x32_bf16.  One stage (32 input channels) is exactly one K = 32 step:
@@ -352,7 +355,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
         const int q = tid & 255, part = tid >> 8;
         const int64_t b = board0 + (q >> 6);
         uint32_t pk[4] = {0, 0, 0, 0};
-        if (b < n_boards) {
+        if (b < n_boards && !(MZ_DIAG & 1)) {
             const uint16_t *px = x + b * tw.cin * 64 + (q & 63);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -362,7 +365,8 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
             }
         }
         *reinterpret_cast<uint4 *>(in + q * 32 + part * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        for (int i = tid; i < FIRST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wf + i * 16) = tw.w_first[i];
+        if (!(MZ_DIAG & 2))
+            for (int i = tid; i < FIRST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wf + i * 16) = tw.w_first[i];
     }
     __syncthreads();
     f32x16 acc[2][2];
@@ -373,7 +377,7 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = bv[i][k >> 2][k & 3];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ((MZ_DIAG & 4) ? 0 : 9); ++tap) {
         const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
         bf16x8 a[2], b[2];
 #pragma unroll
@@ -401,39 +405,32 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
                 uint2 o;   // round, then ReLU on the packed pair (as layer_mid)
                 o.x = relu_bf16x2(pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]));
                 o.y = relu_bf16x2(pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
-                *reinterpret_cast<uint2 *>(p) = o;
+                if (!(MZ_DIAG & 8) || o.x == 0x12345678u) *reinterpret_cast<uint2 *>(p) = o;
             }
         }
     __syncthreads();
 }
 
-struct HeadRegs { uint32_t w1[16], w2[16]; float pv; };   // w: bf16 pairs {input 2i (low), input 2i + 1 (high)}
+struct HeadRegs { bf16x8 a1[4], a2[4]; };   // this wave's weight (A) fragments of the two Linear layers, one per k-step of 32 inputs
 __device__ __forceinline__ float pair_lo(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float pair_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
-// 32-input dot product of a thread's weight pairs with 32 f32 features in LDS, on packed fp32 FMAs (v_pk_fma_f32: two
-// lanes of an even/odd-input accumulator pair per instruction; the library is built with -ffp-contract=off, so the FMA
-// is spelled out).  The Linear layers are VALU-bound: this is a quarter of the instructions of separate mul + add.
-__device__ __forceinline__ float dot32(const uint32_t (&wp)[16], const float *x) {
-    const f32x4 *f = reinterpret_cast<const f32x4 *>(x);
-    f32x2 a = {0.0f, 0.0f};
-#pragma unroll
-    for (int i4 = 0; i4 < 8; ++i4) {
-        const f32x4 v = f[i4];
-        a = __builtin_elementwise_fma(f32x2{pair_lo(wp[2 * i4]), pair_hi(wp[2 * i4])}, f32x2{v[0], v[1]}, a);
-        a = __builtin_elementwise_fma(f32x2{pair_lo(wp[2 * i4 + 1]), pair_hi(wp[2 * i4 + 1])}, f32x2{v[2], v[3]}, a);
-    }
-    return a[0] + a[1];
-}
 
-// every global read of the heads, issued BEFORE the last conv layer so its latency hides under that layer's MFMAs
+// every global read of the heads' weights, issued at the start of heads_batch.
+// Linear weights are bf16 [out][in] row-major (nn.Linear's own layout): wave w owns output rows 16 w .. 16 w + 15, and
+// lane l's A fragment of k-step ks is the 16 bytes at row 16 w + (l & 15), inputs 32 ks + 8 (l >> 4) .. + 7.
 __device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadRegs &hr) {
-    const int grp = tid >> 7, k = tid & 127;
+    const int w = tid >> 6, lane = tid & 63;
+    const int r1 = 16 * w + (lane & 15);
+    const int r2 = r1 < MZ_ACTIONS ? r1 : MZ_ACTIONS - 1;   // Linear(128,65): rows past 64 repeat row 64, their outputs are never read
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hr.w1[i] = hd.p1_wt[(16 * grp + i) * 128 + k];
-    const int k2 = k < MZ_ACTIONS ? k : 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) hr.w2[i] = hd.p2_wt[(16 * grp + i) * MZ_ACTIONS + k2];
-    float pv = 0.0f;   // one small parameter per thread
+    for (int ks = 0; ks < 4; ++ks) {
+        hr.a1[ks] = *reinterpret_cast<const bf16x8 *>(hd.p1_w + r1 * 128 + 32 * ks + 8 * (lane >> 4));
+        hr.a2[ks] = *reinterpret_cast<const bf16x8 *>(hd.p2_w + r2 * 128 + 32 * ks + 8 * (lane >> 4));
+    }
+}
+// the heads' small parameters, one per thread (staged in LDS by heads_batch)
+__device__ __forceinline__ float heads_param(const Heads &hd, int tid) {
+    float pv = 0.0f;
     if (tid < 16) pv = hd.pc_w[tid];
     else if (tid < 18) pv = hd.pc_b[tid - 16];
     else if (tid < 34) pv = hd.vc_w[tid - 18];
@@ -442,7 +439,7 @@ __device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadReg
     else if (tid >= 168 && tid < 168 + MZ_ACTIONS) pv = hd.p2_b[tid - 168];
     else if (tid >= 240 && tid < 368) pv = hd.v1_w[tid - 240];
     else if (tid == 368) pv = hd.v1_b[0];
-    hr.pv = pv;
+    return pv;
 }
 
 // ---- last layer: X -> hidden (global, NCHW, 8 planes) on v_mfma_f32_16x16x32_bf16: the 8 output planes are padded
@@ -450,14 +447,12 @@ __device__ __forceinline__ void heads_prefetch(const Heads &hd, int tid, HeadReg
 // 64-byte-row swizzle as the mid layers) sit in the T region at once; wave w owns positions 32w .. 32w+31 = two
 // 16-position tiles.  D: lane -> position (l & 15), rows co = 4 (l >> 4) + 0..3, i.e. lanes 0..31 hold the 8 real planes.
 template <int OUT_DT>
-__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Heads &hd, HeadRegs &hr, void *__restrict__ hidden,
-                                           int64_t board0, int64_t n_boards, int tid, float (&hv)[2][4]) {
+__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, float (&hv)[2][4]) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     char *wl = lds + OFF_T;
     // this layer's weights were sent to the T image by LDS-DMA during the last mid layer's epilogue (layer_mid, tail_dma):
-    // retire every wave's pieces, then the heads' 65 global reads are requested and stay in flight under the MFMAs below
+    // retire every wave's pieces
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (hd.policy) heads_prefetch(hd, tid, hr);
     acc16_t acc[2] = {acc16_t{0.0f, 0.0f, 0.0f, 0.0f}, acc16_t{0.0f, 0.0f, 0.0f, 0.0f}};
     const int waddr = c16 * 64 + ((kc ^ ((0x78 >> (((c16 >> 2) & 3) * 2)) & 3)) << 4);
     const int x = p16 & 7, y0 = p16 >> 3, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
@@ -484,7 +479,7 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
     TapFrags tf[2];
     load_tap(0, tf[0]);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ((MZ_DIAG & 32) ? 0 : 9); ++tap) {
         if (tap + 1 < 9) load_tap(tap + 1, tf[(tap + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
         const TapFrags &c = tf[tap & 1];
@@ -494,116 +489,258 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, const Hea
             for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.a[kq], c.b[kq][j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = (4 * kc + k) & 7;   // lanes 32..63 hold the padding rows: computed, never stored
+            const float v = fmaxf(acc[j][k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
+            hv[j][k] = OUT_DT == MZ_F32 ? v : bf16_up(bf16_rne(v));  // what store_hidden writes (and the heads read back)
+        }
+    // every wave is done with the X image and the last layer's weights in T: whatever comes next (the heads, or the next
+    // tile's first layer) may overwrite them.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// the hidden state (global, NCHW, 8 planes) from layer_last's registers.  Called LAST in the kernel: nothing waits on
+// these stores (issued before the heads, their completion sat in front of the heads' first counted wait: 1.8k cycles)
+template <int OUT_DT>
+__device__ __forceinline__ void store_hidden(const float (&hv)[2][4], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
+    const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
     const int64_t b = board0 + (w >> 1);
+    if (b >= n_boards || kc >= 2 || (MZ_DIAG & 64)) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int cell = 32 * (w & 1) + 16 * j + p16;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int co = (4 * kc + k) & 7;   // lanes 32..63 hold the padding rows: computed, never stored
-            const float v = fmaxf(acc[j][k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
-            const uint32_t vb = bf16_rne(v);
-            hv[j][k] = OUT_DT == MZ_F32 ? v : bf16_up(vb);  // what the heads see = what is stored
-            if (b < n_boards && kc < 2) {
-                const int64_t o = b * 512 + co * 64 + cell;
-                if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = v;
-                else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)vb;
-            }
+            const int64_t o = b * 512 + (4 * kc + k) * 64 + cell;
+            if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = hv[j][k];
+            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)(__float_as_uint(hv[j][k]) >> 16);
         }
     }
 }
 
-// ---- prediction heads for the tile's 4 boards (network.py:79-111), fp32 VALU; ~100k MACs per tile ------
-// Latency, not arithmetic, is the cost here (every weight comes from L2), so: both Linear layers split
-// their 128 inputs over the four 128-thread groups (thread = one output column x 32 inputs x all 4
-// boards), ALL 64 weights a thread needs are requested up front (two batches in flight while the 1x1
-// convolutions run), and the partial sums meet in LDS.
-// LDS (the X image is dead by now), floats: hid [4][8][64] | fp [4][128] | fv [4][128] | h1 [4][128] |
-// part [4 groups][4 boards][128] | vsum [4]
-__device__ __forceinline__ void heads_tile(char *lds, const Heads &hd, const HeadRegs &hr, const float (&hv)[2][4], int64_t board0,
-                                           int64_t n_boards, int tid) {
-    float *hid = reinterpret_cast<float *>(lds + OFF_X);
-    float *fp = hid + 4 * 512, *fv = fp + 4 * 128, *h1 = fv + 4 * 128, *part = h1 + 4 * 128, *vsum = part + 4 * 4 * 128;
-    float *prm = vsum + 4;   // small parameters: pc_w 16 | pc_b 2 | vc_w 16 | vc_b 2 (pad to 40) | p1_b 128 | p2_b 65 (pad 72) | v1_w 128 | v1_b 1
+// ---- prediction heads (network.py:79-111) for a BATCH of up to 4 tiles = 16 boards of this workgroup ---------------------
+// Run once per tile on the VALU the heads cost 8.6k cycles of an otherwise matrix-bound kernel, and that cost is arithmetic
+// (4 x 25k fp32 MACs + bf16 unpacking per tile; batching alone bought nothing).  Sixteen boards are exactly one MFMA column
+// tile, so the persistent workgroup runs the heads once per FOUR tiles, on the hidden states it stored itself (slot s of the
+// batch = board s & 3 of tile tile0 + (s >> 2) * tstride), with both Linear layers on v_mfma_f32_16x16x32_bf16:
+//   D[out][board] = sum_in W[out][in] * f[in][board],  A = weights (bf16, exact), B = features.
+// The features are fp32 (1x1 conv + ReLU outputs); each goes in as TWO bf16 terms, hi = bf16(f) and lo = bf16(f - hi), two
+// MFMAs per k-step into one fp32 accumulator: 16 significant bits of f survive, products are exact, sums are fp32 -- within
+// 2e-5 of the fp32 module (tests/test_gpu_net.py), where one rounding of f to bf16 would cost 1e-3.
+// LDS (X image region only, dead here): hid f32 [16][8][64] (later: logits f32 [16][80]) | fp hi, lo bf16 [16][136] | fv f32 [16][128] |
+// h1 hi, lo bf16 [16][136] | vsum f32 [16] | prm f32 [512]
+constexpr int HB = 16;     // boards per heads batch
+constexpr int FROW = 136;  // bf16 per feature row (128 + 8 of padding): 272-byte rows put the 16 boards a B-fragment read touches on 16 distinct 4-bank slots
+__device__ __forceinline__ void split_bf16(float f, uint32_t &hi, uint32_t &lo) {   // f >= 0, finite
+    hi = bf16_rne(f);
+    lo = bf16_rne(f - bf16_up(hi));   // exact difference (|f - hi| <= ulp/2), may be negative: rne on the bits is sign-symmetric
+}
+// wave-wide reductions on DPP (six VALU steps, result broadcast from lane 63); __shfl_xor goes through ds_bpermute, and a
+// chain of six of those per reduction is what the softmax of 16 boards was waiting on
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f32<0xB1, 0xF>(0.0f, v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E, 0xF>(0.0f, v);    // quad_perm [2,3,0,1]
+    v += dpp_f32<0x124, 0xF>(0.0f, v);   // row_ror:4
+    v += dpp_f32<0x128, 0xF>(0.0f, v);   // row_ror:8   -> every lane holds its 16-lane row's sum
+    v += dpp_f32<0x142, 0xA>(0.0f, v);   // row_bcast:15 into rows 1, 3
+    v += dpp_f32<0x143, 0xC>(0.0f, v);   // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_f32<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x124, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x128, 0xF>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// The hidden states of the batch's EARLIER tiles come back from global memory (this workgroup stored them, store_hidden, at
+// least one whole tile ago); the loads are issued before the last tile's last layer and land under its MFMAs.  They bypass the
+// CU's L1 (agent-scope relaxed atomic load = global_load sc1).  The batch's last tile hands its values over in registers.
+template <int OUT_DT>
+struct Readback {
+    static constexpr int NW = OUT_DT == MZ_F32 ? 512 : 256;   // dwords per board
+    static constexpr int R = 12 * NW / 512;                   // dwords per thread for 3 earlier tiles = 12 boards
+    uint32_t v[R];
+    float pv;   // this thread's small head parameter (heads_param), requested with the readback
+};
+template <int OUT_DT>
+__device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads &hd, const void *hidden, int64_t tile0, int64_t tstride, int nprev, int tid) {
+    constexpr int NW = Readback<OUT_DT>::NW;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own earlier stores (long complete: a formality that costs nothing here)
+#pragma unroll
+    for (int r = 0; r < Readback<OUT_DT>::R; ++r) {
+        const int i = tid + 512 * r, slot = i / NW;
+        const int sl = slot < 4 * nprev ? slot : 0;    // unused slots re-read the batch's first board (valid) and are ignored later
+        const int64_t b = (tile0 + (int64_t)(sl >> 2) * tstride) * TILE_BOARDS + (sl & 3);
+        rb.v[r] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(hidden) + b * NW + (i % NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    rb.pv = heads_param(hd, tid);
+}
+
+template <int OUT_DT>
+__device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Readback<OUT_DT> &rb, const float (&hv)[2][4], int64_t n_boards,
+                                            int64_t tile0, int64_t tstride, int ntiles, int tid, long long *stamps) {
+#define MZ_HSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    float *hid = reinterpret_cast<float *>(lds);
+    uint16_t *fph = reinterpret_cast<uint16_t *>(lds + 32768), *fpl = reinterpret_cast<uint16_t *>(lds + 37376);   // [16][FROW] bf16 = 4,352 B each
+    float *fv = reinterpret_cast<float *>(lds + 41984);                                                            // [16][128] f32
+    uint16_t *h1h = reinterpret_cast<uint16_t *>(lds + 50176), *h1l = reinterpret_cast<uint16_t *>(lds + 54784);
+    float *logit = hid;   // [16][80]: the hid rows are dead once the 1x1 convs are through (two barriers before the logits are written)
+    float *vsum = reinterpret_cast<float *>(lds + 59392);
+    float *prm = vsum + HB;   // small parameters: pc_w 16 | pc_b 2 | vc_w 16 | vc_b 2 (pad to 40) | p1_b 128 | p2_b 65 (pad 72) | v1_w 128 | v1_b 1
     float *s_pc_w = prm, *s_pc_b = prm + 16, *s_vc_w = prm + 18, *s_vc_b = prm + 34, *s_p1_b = prm + 40, *s_p2_b = prm + 168, *s_v1_w = prm + 240,
           *s_v1_b = prm + 368;
-    const int w = tid >> 6, lane = tid & 63;
-    const int grp = tid >> 7, k = tid & 127;   // input group / board (wave-uniform), output column
-    const uint32_t(&w1)[16] = hr.w1;
-    const uint32_t(&w2)[16] = hr.w2;
-    __syncthreads();  // every wave is done reading X
-    prm[tid] = hr.pv;
-    if (lane < 32) {   // layer_last's D layout: lane -> cell col_cell(lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
+    static_assert(59392 + (HB + 512) * 4 <= ACT_BYTES && HB * FROW * 2 <= 4608, "the heads stay inside the X image region");
+    const int w = tid >> 6, lane = tid & 63, n16 = lane & 15, kc = lane >> 4;
+    const int grp = tid >> 7, k = tid & 127;
+    const int nb = 4 * ntiles;                 // slots in use
+    auto board_of = [&](int s) { return (tile0 + (int64_t)(s >> 2) * tstride) * TILE_BOARDS + (s & 3); };
+    MZ_HSTAMP(19);
+    if (MZ_DIAG & 128) return;   // (diagnostic)
+    // no barrier needed before these LDS writes: layer_last ended with one, and nothing has touched LDS since
+    {   // earlier tiles: the readback registers; unused slots are zero-filled
+        constexpr int NW = Readback<OUT_DT>::NW;
+#pragma unroll
+        for (int r = 0; r < Readback<OUT_DT>::R; ++r) {
+            const int i = tid + 512 * r;
+            const uint32_t v = (i / NW) < nb - 4 ? rb.v[r] : 0u;
+            if (OUT_DT == MZ_F32) hid[i] = __uint_as_float(v);
+            else *reinterpret_cast<float2 *>(hid + 2 * i) = make_float2(bf16_up(v & 0xFFFFu), bf16_up(v >> 16));
+        }
+        for (int i = 12 * 512 + tid; i < HB * 512; i += 512) hid[i] = 0.0f;   // slots 12..15 (overwritten below when the batch is full)
+    }
+    // every global read of the heads' weights is requested here, BEHIND the staging above (the memory queue is in order: a
+    // wait for the readback must not also wait for these); the matrices are consumed two phases later
+    HeadRegs hr;
+    heads_prefetch(hd, tid, hr);
+    prm[tid] = rb.pv;
+    __syncthreads();
+    if (lane < 32) {   // the batch's last tile, from layer_last's D layout: lane -> cell col_cell(lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
+        float *dst = hid + (nb - 4 + (w >> 1)) * 512;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hid[(w >> 1) * 512 + (4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + col_cell(lane & 15)] = hv[j][q];
+            for (int q = 0; q < 4; ++q) dst[(4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + col_cell(lane & 15)] = hv[j][q];
     }
     __syncthreads();
-    {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); here grp = board
+    MZ_HSTAMP(21);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // 1x1 convs 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8)); thread group = board 4 r + grp
+        const int s = 4 * r + grp;
         const int c2 = k >> 6, pos = k & 63;
         float ap = s_pc_b[c2], av = s_vc_b[c2];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float x = hid[grp * 512 + c * 64 + pos];
-            ap += s_pc_w[c2 * 8 + c] * x;
-            av += s_vc_w[c2 * 8 + c] * x;
+            const float xv = hid[s * 512 + c * 64 + pos];
+            ap += s_pc_w[c2 * 8 + c] * xv;
+            av += s_vc_w[c2 * 8 + c] * xv;
         }
-        fp[grp * 128 + k] = fmaxf(ap, 0.0f);
-        fv[grp * 128 + k] = fmaxf(av, 0.0f);
+        uint32_t hi, lo;
+        split_bf16(fmaxf(ap, 0.0f), hi, lo);
+        fph[s * FROW + k] = (uint16_t)hi;
+        fpl[s * FROW + k] = (uint16_t)lo;
+        fv[s * 128 + k] = fmaxf(av, 0.0f);
     }
     __syncthreads();
-    {   // Linear(128,128): partial sums over inputs 32 grp .. 32 grp + 31, all 4 boards
+    MZ_HSTAMP(22);
+    {   // Linear(128,128) + ReLU: wave w = output rows 16 w .. + 15, all 16 boards; D: lane -> board n16, rows 16 w + 4 kc + 0..3
+        bf16x8 bh[4], bl[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            part[(grp * 4 + b) * 128 + k] = dot32(w1, fp + b * 128 + 32 * grp);
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[ks] = *reinterpret_cast<const bf16x8 *>(fph + n16 * FROW + 32 * ks + 8 * kc);
+            bl[ks] = *reinterpret_cast<const bf16x8 *>(fpl + n16 * FROW + 32 * ks + 8 * kc);
         }
-        if (w < 4) {   // value Linear(128,1): wave w = board w
-            float v = s_v1_w[lane] * fv[w * 128 + lane] + s_v1_w[lane + 64] * fv[w * 128 + lane + 64];
+        acc16_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) vsum[w] = v;
+        for (int ks = 0; ks < 4; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hr.a1[ks], bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hr.a1[ks], bl[ks], acc, 0, 0, 0);
         }
-    }
-    __syncthreads();
-    h1[grp * 128 + k] = fmaxf(s_p1_b[k] + part[(0 * 4 + grp) * 128 + k] + part[(1 * 4 + grp) * 128 + k] + part[(2 * 4 + grp) * 128 + k] +
-                                  part[(3 * 4 + grp) * 128 + k], 0.0f);   // here grp = board
-    __syncthreads();
-    if (k < MZ_ACTIONS) {   // Linear(128,65) partial sums
+        uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            part[(grp * 4 + b) * 128 + k] = dot32(w2, h1 + b * 128 + 32 * grp);
-        }
-    }
-    __syncthreads();
-    if (w < 4 && board0 + w < n_boards) {   // softmax over 65 (one wave per board), tanh
-        auto logit = [&](int a) { return s_p2_b[a] + part[(0 * 4 + w) * 128 + a] + part[(1 * 4 + w) * 128 + a] + part[(2 * 4 + w) * 128 + a] + part[(3 * 4 + w) * 128 + a]; };
-        const float x = logit(lane), x64 = logit(64);
-        float m = fmaxf(x, x64);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        const float e = expf(x - m), e64 = expf(x64 - m);
-        float sum = e;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        sum += e64;
-        float *pol = hd.policy + (board0 + w) * MZ_ACTIONS;
-        pol[lane] = e / sum;
+        for (int q = 0; q < 4; ++q) split_bf16(fmaxf(acc[q] + s_p1_b[16 * w + 4 * kc + q], 0.0f), hi[q], lo[q]);
+        *reinterpret_cast<uint2 *>(h1h + n16 * FROW + 16 * w + 4 * kc) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+        *reinterpret_cast<uint2 *>(h1l + n16 * FROW + 16 * w + 4 * kc) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+        // value Linear(128,1): wave w = boards w and w + 8
+        const float v0 = wave_sum_dpp(s_v1_w[lane] * fv[w * 128 + lane] + s_v1_w[lane + 64] * fv[w * 128 + lane + 64]);
+        const float v1 = wave_sum_dpp(s_v1_w[lane] * fv[(w + 8) * 128 + lane] + s_v1_w[lane + 64] * fv[(w + 8) * 128 + lane + 64]);
         if (lane == 0) {
-            pol[64] = e64 / sum;
-            hd.value[board0 + w] = tanhf(vsum[w] + s_v1_b[0]);
+            vsum[w] = v0;
+            vsum[w + 8] = v1;
         }
     }
+    __syncthreads();
+    if (w < 5) {   // Linear(128,65): output rows 16 w .. + 15 (rows past 64 are padding)
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[ks] = *reinterpret_cast<const bf16x8 *>(h1h + n16 * FROW + 32 * ks + 8 * kc);
+            bl[ks] = *reinterpret_cast<const bf16x8 *>(h1l + n16 * FROW + 32 * ks + 8 * kc);
+        }
+        acc16_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hr.a2[ks], bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hr.a2[ks], bl[ks], acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4 *>(logit + n16 * 80 + 16 * w + 4 * kc) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    MZ_HSTAMP(23);
+    {   // softmax over 65 + tanh: wave w = boards w and w + 8, the two chains interleaved
+        float x[2], x64[2], m[2], e[2], e64[2], sum[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = w + 8 * h;
+            x[h] = s_p2_b[lane] + logit[s * 80 + lane];
+            x64[h] = s_p2_b[64] + logit[s * 80 + 64];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) m[h] = wave_max_dpp(fmaxf(x[h], x64[h]));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            e[h] = expf(x[h] - m[h]);
+            e64[h] = expf(x64[h] - m[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) sum[h] = wave_sum_dpp(e[h]) + e64[h];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = w + 8 * h;
+            const int64_t b = board_of(s);
+            if (s >= nb || b >= n_boards) continue;
+            float *pol = hd.policy + b * MZ_ACTIONS;
+            pol[lane] = e[h] / sum[h];
+            if (lane == 0) {
+                pol[64] = e64[h] / sum[h];
+                hd.value[b] = tanhf(vsum[s] + s_v1_b[0]);
+            }
+        }
+    }
+    // no trailing barrier: everything above lives in the X image region, which the next tile writes only behind its
+    // first layer's own __syncthreads()
 }
 
+// one 4-board tile through the convolution tower: first layer, three residual blocks, last layer, hidden state stored
 template <int OUT_DT>
-__global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_t *__restrict__ x, void *__restrict__ hidden, int64_t n_boards) {
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const Heads &hd, const uint16_t *__restrict__ x, void *__restrict__ hidden,
+                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[2][4]) {
+    Tower tw = tw_;
+    if (tw.stamps) tw.stamps += tile * 24;   // this tile's row of the diagnostics array
     const uint32_t vm = halo_mask(tid & 31);
-    const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
+    const int64_t board0 = tile * TILE_BOARDS;
     MZ_STAMP(tw, 0);
-    if (tw.stamps && threadIdx.x == 0) tw.stamps[(int64_t)blockIdx.x * 24 + 17] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (tw.stamps && threadIdx.x == 0) tw.stamps[17] = (long long)__builtin_amdgcn_s_memrealtime();
     mid_prologue(lds, tw.w_mid, tid);
     f32x4 bv[4];   // bias of the first mid layer in the K loop's accumulator layout (see layer_mid)
 #pragma unroll
@@ -621,13 +758,68 @@ __global__ void __launch_bounds__(512) k_tower(Tower tw, Heads hd, const uint16_
                          5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
-    float hv[2][4];
-    HeadRegs hr;
-    layer_last<OUT_DT>(lds, tw, hd, hr, hidden, board0, n_boards, tid, hv);
+    asm volatile("" : "+v"(tid));   // lane-derived addresses of the phases below are computed HERE, not held across the K loops
+    if (nprev >= 0) readback_issue<OUT_DT>(rb, hd, hidden, tile - nprev * tstride, tstride, nprev, tid);   // the heads follow this tile
+    layer_last<OUT_DT>(lds, tw, tid, hv);
     MZ_STAMP(tw, 15);
-    if (hd.policy) heads_tile(lds, hd, hr, hv, board0, n_boards, tid);
-    MZ_STAMP(tw, 16);
-    if (tw.stamps && threadIdx.x == 0) tw.stamps[(int64_t)blockIdx.x * 24 + 18] = (long long)__builtin_amdgcn_s_memrealtime();
+    // a tile that the heads follow stores its hidden state AFTER them (its stores would otherwise sit in the memory queue in
+    // front of the heads' weight loads, and a wait for those would wait for the stores' completion too)
+    if (nprev < 0) store_hidden<OUT_DT>(hv, hidden, board0, n_boards, tid);
+}
+
+// Persistent grid: one workgroup per CU walks its tiles (tile = blockIdx.x, += gridDim.x), which saves the workgroup
+// turnovers a 1024-workgroup launch pays on every CU (all 160 KB of LDS per workgroup: never two resident at once).
+// The arguments are NOT kept in registers across the tile loop: each iteration re-reads them from the kernarg segment
+// (scalar loads, cached) through a pointer the compiler cannot see through, and the lane id is laundered the same way, so no
+// address or pointer computed for one tile stays live into the K loops of the next (a plain loop spills: 20 pointers and
+// the per-lane LDS addresses of every phase would be hoisted and held).
+struct KArgs { Tower tw; Heads hd; const uint16_t *x; void *hidden; int64_t n_boards; };
+typedef const __attribute__((address_space(4))) char *kptr_t;
+template <class T>
+__device__ __forceinline__ T karg(kptr_t base, size_t off) { return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + off); }
+
+template <int OUT_DT>
+__global__ void __launch_bounds__(512) k_tower(KArgs) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    int in_batch = 0;   // tiles of this workgroup whose heads are still to run
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x;; tile += gridDim.x) {
+        kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int64_t n_boards = karg<int64_t>(ka, offsetof(KArgs, n_boards));
+        if (tile * TILE_BOARDS >= n_boards) break;
+        const Tower tw{karg<const uint4 *>(ka, offsetof(KArgs, tw.w_first)), karg<const float *>(ka, offsetof(KArgs, tw.b_first)),
+                       karg<const uint4 *>(ka, offsetof(KArgs, tw.w_mid)),   karg<const float *>(ka, offsetof(KArgs, tw.b_mid)),
+                       karg<const uint4 *>(ka, offsetof(KArgs, tw.w_last)),  karg<const float *>(ka, offsetof(KArgs, tw.b_last)),
+                       karg<int>(ka, offsetof(KArgs, tw.cin)),               karg<long long *>(ka, offsetof(KArgs, tw.stamps))};
+        const Heads hd{karg<const float *>(ka, offsetof(KArgs, hd.pc_w)),    karg<const float *>(ka, offsetof(KArgs, hd.pc_b)),
+                       karg<const uint16_t *>(ka, offsetof(KArgs, hd.p1_w)), karg<const float *>(ka, offsetof(KArgs, hd.p1_b)),
+                       karg<const uint16_t *>(ka, offsetof(KArgs, hd.p2_w)), karg<const float *>(ka, offsetof(KArgs, hd.p2_b)),
+                       karg<const float *>(ka, offsetof(KArgs, hd.vc_w)),    karg<const float *>(ka, offsetof(KArgs, hd.vc_b)),
+                       karg<const float *>(ka, offsetof(KArgs, hd.v1_w)),    karg<const float *>(ka, offsetof(KArgs, hd.v1_b)),
+                       karg<float *>(ka, offsetof(KArgs, hd.value)),         karg<float *>(ka, offsetof(KArgs, hd.policy))};
+        // the heads run once per batch of four tiles (heads_batch): after this tile if it is the batch's fourth or the workgroup's last
+        const bool heads_now = hd.policy != nullptr && (in_batch == 3 || (tile + gridDim.x) * TILE_BOARDS >= n_boards);
+        void *hidden = karg<void *>(ka, offsetof(KArgs, hidden));
+        Readback<OUT_DT> rb;
+        float hv[2][4];
+        tower_tile<OUT_DT>(lds, tw, hd, karg<const uint16_t *>(ka, offsetof(KArgs, x)), hidden, n_boards, tile, tid, rb, heads_now ? in_batch : -1, gridDim.x, hv);
+        ++in_batch;
+        if (heads_now) {
+            asm volatile("" : "+v"(tid));
+            heads_batch<OUT_DT>(lds, hd, rb, hv, n_boards, tile - (int64_t)(in_batch - 1) * gridDim.x, gridDim.x, in_batch, tid,
+                                tw.stamps ? tw.stamps + tile * 24 : nullptr);
+            store_hidden<OUT_DT>(hv, hidden, tile * TILE_BOARDS, n_boards, tid);
+            in_batch = 0;
+        }
+        if (tw.stamps && threadIdx.x == 0) {   // diagnostics: end of this tile (and of its batch's heads, when they ran here)
+            tw.stamps[tile * 24 + 16] = (long long)__builtin_readcyclecounter();
+            tw.stamps[tile * 24 + 18] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+        // between tiles no further barrier is needed: layer_last ends with one, and heads_batch stays inside the X image region
+    }
 }
 
 }  // namespace
@@ -646,13 +838,25 @@ static int launch_tower(const char *who, const mz_tower_weights *w, const mz_hea
              (long long *)w->debug_stamps};
     Heads hd{};
     if (hw) {
-        MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_wt && hw->p1_b && hw->p2_wt && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,
+        MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_w && hw->p1_b && hw->p2_w && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,
                    "%s: null head pointer", who);
-        hd = Heads{hw->pc_w, hw->pc_b, hw->p1_wt, hw->p1_b, hw->p2_wt, hw->p2_b, hw->vc_w, hw->vc_b, hw->v1_w, hw->v1_b, value, policy};
+        hd = Heads{hw->pc_w, hw->pc_b, (const uint16_t *)hw->p1_w, hw->p1_b, (const uint16_t *)hw->p2_w, hw->p2_b, hw->vc_w, hw->vc_b, hw->v1_w, hw->v1_b, value, policy};
     }
-    const dim3 grid((unsigned)((n + TILE_BOARDS - 1) / TILE_BOARDS)), block(512);
-    if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, tw, hd, (const uint16_t *)x, hidden, n);
-    else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, tw, hd, (const uint16_t *)x, hidden, n);
+    const int64_t n_tiles = (n + TILE_BOARDS - 1) / TILE_BOARDS;
+#ifndef MZ_PERSIST
+#define MZ_PERSIST 1
+#endif
+    int64_t n_wg = n_tiles;
+    if (MZ_PERSIST) {   // one workgroup per CU (each takes all of a CU's LDS), walking tiles wg, wg + n_wg, ...
+        int dev = 0, cus = 0;
+        MZ_HIP(hipGetDevice(&dev));
+        MZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (cus > 0 && n_wg > cus) n_wg = cus;
+    }
+    const dim3 grid((unsigned)n_wg), block(512);
+    const KArgs ka{tw, hd, (const uint16_t *)x, hidden, n};
+    if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, ka);
+    else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, ka);
     MZ_LAUNCH_CHECK("k_tower");
     return MZ_OK;
 }

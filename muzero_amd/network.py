@@ -209,12 +209,12 @@ class InferenceEngine:
 
     def _pack_heads(self):
         """prediction heads (network.py:79-111) as the arrays of mz_heads_weights: f32, except the two Linear matrices,
-        which go as bf16 input pairs [in / 2][out][2] (the serving network's weights ARE bf16 values: lossless)"""
+        which go as bf16 [out][in] (the serving network's weights ARE bf16 values: lossless)"""
         ph, vh = self.net.prediction.policy_head, self.net.prediction.value_head
         f = lambda t: t.detach().float().contiguous()  # noqa: E731
-        pairs = lambda w: w.detach().to(torch.bfloat16).t().reshape(w.shape[1] // 2, 2, w.shape[0]).permute(0, 2, 1).contiguous()  # noqa: E731
-        return dict(pc_w=f(ph[0].weight.reshape(2, 8)), pc_b=f(ph[0].bias), p1_wt=pairs(ph[3].weight), p1_b=f(ph[3].bias),
-                    p2_wt=pairs(ph[5].weight), p2_b=f(ph[5].bias), vc_w=f(vh[0].weight.reshape(2, 8)), vc_b=f(vh[0].bias),
+        lin = lambda w: w.detach().to(torch.bfloat16).contiguous()  # noqa: E731
+        return dict(pc_w=f(ph[0].weight.reshape(2, 8)), pc_b=f(ph[0].bias), p1_w=lin(ph[3].weight), p1_b=f(ph[3].bias),
+                    p2_w=lin(ph[5].weight), p2_b=f(ph[5].bias), vc_w=f(vh[0].weight.reshape(2, 8)), vc_b=f(vh[0].bias),
                     v1_w=f(vh[3].weight.reshape(128)), v1_b=f(vh[3].bias))
 
     def _repack(self):

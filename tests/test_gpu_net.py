@@ -133,11 +133,11 @@ def test_hip_tower_weight_publish():
     eng = InferenceEngine(Network(), 8, torch.bfloat16, tower="hip")
     x10 = torch.rand(8, 10, 8, 8, device="cuda").to(torch.bfloat16)
     h0 = eng.recurrent(x10)[2].clone()
-    ptrs = {k: v.get("w_mid", v.get("p1_wt")).data_ptr() for k, v in eng._packs.items()}
+    ptrs = {k: v.get("w_mid", v.get("p1_w")).data_ptr() for k, v in eng._packs.items()}
     torch.manual_seed(2)
     new = Network()
     eng.load_weights(new.state_dict())
-    assert ptrs == {k: v.get("w_mid", v.get("p1_wt")).data_ptr() for k, v in eng._packs.items()} and len(ptrs) == 3
+    assert ptrs == {k: v.get("w_mid", v.get("p1_w")).data_ptr() for k, v in eng._packs.items()} and len(ptrs) == 3
     v1, p1, h1 = eng.recurrent(x10)
     fresh = InferenceEngine(new, 8, torch.bfloat16, tower="hip")
     vf, pf, hf = fresh.recurrent(x10)

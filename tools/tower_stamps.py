@@ -31,3 +31,20 @@ for i, n in enumerate(names):
 print("%-18s mean %9.0f" % ("total per block", tot.mean()))
 rt = (s[:, 18] - s[:, 17])
 print("in-kernel clock: %.3f GHz (shader cycles / 100 MHz real-time ticks, median over blocks)" % float((tot / rt).median() * 0.1))
+# where the launch's wall time goes (s_memrealtime, 10 ns ticks): whole-kernel span vs the tiles' own durations
+r0, r1 = s[:, 17], s[:, 18]
+span = float(r1.max() - r0.min()) * 0.01
+dur = (r1 - r0) * 0.01
+print("kernel span first start -> last end: %.1f us; tile duration mean %.1f us (min %.1f, max %.1f); tiles per CU %.2f" %
+      (span, float(dur.mean()), float(dur.min()), float(dur.max()), nb / 256.0))
+order = torch.argsort(r0)
+starts = (r0[order] - r0.min()) * 0.01
+print("tile start times (us) at ranks 0, 255, 256, 511, 512, 767, 768, last: " + ", ".join("%.1f" % float(starts[min(i, nb - 1)]) for i in (0, 255, 256, 511, 512, 767, 768, nb - 1)))
+ends = (torch.sort(r1).values - r0.min()) * 0.01
+print("tile end times (us) at ranks 0, 255, 256, 767, 768, last: " + ", ".join("%.1f" % float(ends[min(i, nb - 1)]) for i in (0, 255, 256, 767, 768, nb - 1)))
+# heads batch internals (stamps 19, 21..23 of the tiles whose heads ran): staging | 1x1 convs | Linear 1+2 | softmax
+hb = s[s[:, 19] > 0]
+if len(hb):
+    seg = torch.stack([hb[:, 21] - hb[:, 19], hb[:, 22] - hb[:, 21], hb[:, 23] - hb[:, 22], hb[:, 16] - hb[:, 23], hb[:, 19] - hb[:, 15]], 1)
+    print("heads batch (%d batches): staging %.0f | 1x1 convs %.0f | Linear layers %.0f | softmax+out %.0f | (last layer end -> heads start %.0f)"
+          % ((len(hb),) + tuple(float(x) for x in seg.mean(0))))
