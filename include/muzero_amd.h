@@ -300,7 +300,7 @@ typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muz
                               16-byte chunk c of the 32 input channels stored in slot c ^ {0,2,3,1}[(co >> 2) & 3];
                               followed by 4 stages (32 KB) of padding: the weight stream prefetches 4 stages ahead */
     const float *b_mid;    /* f32 [6][128] */
-    const void *w_last;    /* bf16 [36 stages][16 co (rows 8..15 zero)][4 slots][8]: stages and chunk swizzle as w_mid */
+    const void *w_last;    /* bf16 [4 quarters of ci][80 rows = tap * 8 + plane (rows 72..79 zero)][4 slots][8]: chunk swizzle as w_mid */
     const float *b_last;   /* f32 [8] or NULL (network.py:127) */
     int32_t cin;           /* input planes: 9 (Representation) or 10 (Dynamics: hidden ++ action planes) */
     int64_t *debug_stamps; /* diagnostics, normally NULL: device array [ceil(n/4)][24] receiving s_memtime stamps at the

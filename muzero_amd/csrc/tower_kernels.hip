@@ -54,14 +54,16 @@ constexpr int OFF_Z = LDS_BYTES;  // the halo's zero fragment: a DS read at or b
                                   // (hardware bounds check; the allocation is the whole 160 KB, so nothing lies behind it)
 constexpr int N_STAGES = 36;                   // 9 taps x 4 quarters of the input channels
 constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
-constexpr int LAST_W_BYTES = 36 * 16 * 32 * 2;  // 36,864
+constexpr int LAST_ROWS = 80;                       // 9 taps x 8 planes = 72 weight rows, padded to five 16-row MFMA tiles
+constexpr int LAST_W_BYTES = 4 * LAST_ROWS * 32 * 2;  // 20,480: [4 channel quarters][80 rows][32 ci]
+constexpr int OFF_P = OFF_T + LAST_W_BYTES;         // the last layer's per-tap partial sums: 72 KB spanning the rest of T and the weight ring
 
 struct Tower {
     const uint4 *w_first;  // [9][128 co][16 ci] bf16
     const float *b_first;  // [128] or null
     const uint4 *w_mid;    // [6][36][128 co][4 slots][8] bf16, slot = chunk ^ {0,2,3,1}[(co >> 2) & 3]; + 4 stages of padding
     const float *b_mid;    // [6][128]
-    const uint4 *w_last;   // [36][16 co (8 real)][4 slots][8] bf16, same swizzle as w_mid
+    const uint4 *w_last;   // [4 quarters][80 rows = tap * 8 + plane (72 real)][4 slots][8] bf16, same 64-byte-row swizzle as w_mid
     const float *b_last;   // [8] or null
     int cin;               // real input planes (9 or 10)
     long long *stamps;     // diagnostics: [blocks][24] s_memtime stamps at the phase boundaries (null = off)
@@ -286,12 +288,12 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     }
 
     MZ_STAMP(tw, stamp_id);
-    // behind the last mid layer: the LAST conv layer's 36 weight stages (36 KB, already in LDS order) go into the T image by
+    // behind the last mid layer: the LAST conv layer's weights (20 KB, already in LDS order) go into the T image by
     // LDS-DMA now, under this epilogue.  T is free: after the K loop's last barrier no wave reads it any more (stage 35's
     // fragments were read during stage 34, and the "tap 9" prefetch reads the zero block).
     if (tail_dma) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const int piece = w + 8 * k;   // 1 KB pieces, wave-uniform
             if (piece < LAST_W_BYTES / 1024)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tail_dma + piece * 64 + lane),
@@ -442,82 +444,94 @@ __device__ __forceinline__ float heads_param(const Heads &hd, int tid) {
     return pv;
 }
 
-// ---- last layer: X -> hidden (global, NCHW, 8 planes) on v_mfma_f32_16x16x32_bf16: the 8 output planes are padded
-// to ONE 16-row tile (a 32x32 tile would waste 3/4 of the MFMA).  All 36 weight stages [16 co][32 ci] (36 KB, same
-// 64-byte-row swizzle as the mid layers) sit in the T region at once; wave w owns positions 32w .. 32w+31 = two
-// 16-position tiles.  D: lane -> position (l & 15), rows co = 4 (l >> 4) + 0..3, i.e. lanes 0..31 hold the 8 real planes.
+// ---- last layer: X -> hidden (8 planes), with the nine taps in the M dimension -------------------------------------------
+//   P[tap * 8 + plane][pos] = sum_ci W[tap][plane][ci] * X[pos][ci]        one GEMM, M = 72 (padded 80), N = 256, K = 128
+//   hidden[plane][pos]      = relu(b[plane] + sum_tap P[tap * 8 + plane][pos + shift(tap)])     (positions off the board: 0)
+// With the taps in K (as the mid layers have them) a 16-row MFMA tile would carry 8 real rows and every activation row would
+// be fetched from LDS nine times; here each wave reads its 32 positions ONCE (8 fragments) and all 20 weight fragments
+// (28 ds_read_b128 instead of 108, 40 MFMAs instead of 72), writes its 72 x 32 block of fp32 partial sums to LDS, and after
+// one barrier every thread sums the nine shifted taps of one position x four planes.  The layer was LDS-bandwidth bound.
+//   LDS: weights [4 quarters][80 rows][32 ci] at OFF_T (sent there by LDS-DMA under the last mid epilogue); P at OFF_P as
+//   [tap][plane half][pos][4 planes] fp32 (16-byte entries: conflict-free for the writers and the readers).
+// Output: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3 in hv[0..3] (what store_hidden writes and the heads read).
 template <int OUT_DT>
-__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, float (&hv)[2][4]) {
+__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, float (&hv)[4]) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
-    char *wl = lds + OFF_T;
-    // this layer's weights were sent to the T image by LDS-DMA during the last mid layer's epilogue (layer_mid, tail_dma):
-    // retire every wave's pieces
+    const char *wl = lds + OFF_T;
+    float *P = reinterpret_cast<float *>(lds + OFF_P);
+    static_assert(OFF_P + 9 * 2 * 256 * 16 <= LDS_BYTES, "the partial sums fit behind the last layer's weights");
+    // the weights were sent to T during the last mid layer's epilogue (layer_mid, tail_dma): retire every wave's pieces
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    acc16_t acc[2] = {acc16_t{0.0f, 0.0f, 0.0f, 0.0f}, acc16_t{0.0f, 0.0f, 0.0f, 0.0f}};
-    const int waddr = c16 * 64 + ((kc ^ ((0x78 >> (((c16 >> 2) & 3) * 2)) & 3)) << 4);
-    const int x = p16 & 7, y0 = p16 >> 3, yb = 4 * (w & 1);   // tile j = board rows yb + 2j, yb + 2j + 1
-    // one tap = 4 k-steps = 12 fragments; the next tap's fragments are read (fenced) before this tap's 8 MFMAs issue
-    struct TapFrags { bf16x8 a[4], b[4][2]; };
-    auto load_tap = [&](int tap, TapFrags &f) {
-        const int ky = tap / 3, kx = tap % 3;
-        const int dq = (ky - 1) * 8 + (kx - 1);
-        int arow[2], ak4[2];
+    bf16x8 bf[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = 32 * w + 16 * j + p16;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) bf[j][kq] = lds_frag(lds + OFF_X + q * 256 + (((4 * kq + kc) ^ act_key(q)) << 4));
+    }
+    acc16_t acc[5][2];
+#pragma unroll
+    for (int m = 0; m < ((MZ_DIAG & 32) ? 0 : 5); ++m) {
+        const int row = 16 * m + c16;
+        const int waddr = row * 64 + ((kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 4);
+        bf16x8 af[4];
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) af[kq] = lds_frag(wl + kq * (LAST_ROWS * 64) + waddr);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int q2 = (32 * w + 16 * j + p16 + dq) & 255;
-            const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(yb + 2 * j + y0 + ky - 1) < 8u;
-            arow[j] = ok ? OFF_X + q2 * 256 : OFF_Z;
-            ak4[j] = (kc ^ act_key(q2)) << 4;
+            acc[m][j] = acc16_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kq], bf[j][kq], acc[m][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            f.a[kq] = lds_frag(wl + (tap * 4 + kq) * 1024 + waddr);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) f.b[kq][j] = lds_frag(lds + arow[j] + ((kq * 64) ^ ak4[j]));
-        }
-    };
-    TapFrags tf[2];
-    load_tap(0, tf[0]);
-#pragma unroll
-    for (int tap = 0; tap < ((MZ_DIAG & 32) ? 0 : 9); ++tap) {
-        if (tap + 1 < 9) load_tap(tap + 1, tf[(tap + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        const TapFrags &c = tf[tap & 1];
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.a[kq], c.b[kq][j], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     }
+    // D: lane -> position (its column), rows 16 m + 4 kc + 0..3 = tap 2 m + (kc >> 1), planes 4 (kc & 1) + 0..3
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int m = 0; m < ((MZ_DIAG & 32) ? 0 : 5); ++m) {
+        const int tap = 2 * m + (kc >> 1);
+        if (tap < 9) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 32 * w + 16 * j + p16;
+                *reinterpret_cast<f32x4 *>(P + ((tap * 2 + (kc & 1)) * 256 + q) * 4) = f32x4{acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {   // gather the nine shifted taps: thread -> position q, plane half h
+        const int q = tid & 255, h = tid >> 8, x = q & 7, y = (q >> 3) & 7;
+        f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (tw.b_last) sum = *reinterpret_cast<const f32x4 *>(tw.b_last + 4 * h);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(y + ky - 1) < 8u;
+            const int q2 = (q + (ky - 1) * 8 + (kx - 1)) & 255;
+            const f32x4 pv = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + h) * 256 + q2) * 4);
+            if (ok) sum += pv;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int co = (4 * kc + k) & 7;   // lanes 32..63 hold the padding rows: computed, never stored
-            const float v = fmaxf(acc[j][k] + (tw.b_last ? tw.b_last[co] : 0.0f), 0.0f);
-            hv[j][k] = OUT_DT == MZ_F32 ? v : bf16_up(bf16_rne(v));  // what store_hidden writes (and the heads read back)
+            const float v = fmaxf(sum[k], 0.0f);
+            hv[k] = OUT_DT == MZ_F32 ? v : bf16_up(bf16_rne(v));   // what store_hidden writes (and the heads read back)
         }
-    // every wave is done with the X image and the last layer's weights in T: whatever comes next (the heads, or the next
-    // tile's first layer) may overwrite them.
+    }
+    // every wave is done with the X image, the last layer's weights and P: whatever comes next (the heads, or the next
+    // tile's first layer and weight prologue) may overwrite them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// the hidden state (global, NCHW, 8 planes) from layer_last's registers.  Called LAST in the kernel: nothing waits on
-// these stores (issued before the heads, their completion sat in front of the heads' first counted wait: 1.8k cycles)
+// the hidden state (global, NCHW, 8 planes) from layer_last's registers: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3;
+// consecutive lanes write consecutive cells of one plane.  Nothing in the kernel waits on these stores.
 template <int OUT_DT>
-__device__ __forceinline__ void store_hidden(const float (&hv)[2][4], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
-    const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
-    const int64_t b = board0 + (w >> 1);
-    if (b >= n_boards || kc >= 2 || (MZ_DIAG & 64)) return;
+__device__ __forceinline__ void store_hidden(const float (&hv)[4], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
+    const int q = tid & 255, h = tid >> 8;
+    const int64_t b = board0 + (q >> 6);
+    if (b >= n_boards || (MZ_DIAG & 64)) return;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cell = 32 * (w & 1) + 16 * j + p16;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t o = b * 512 + (4 * kc + k) * 64 + cell;
-            if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = hv[j][k];
-            else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)(__float_as_uint(hv[j][k]) >> 16);
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int64_t o = b * 512 + (4 * h + k) * 64 + (q & 63);
+        if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = hv[k];
+        else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)(__float_as_uint(hv[k]) >> 16);
     }
 }
 
@@ -588,7 +602,7 @@ __device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads
 }
 
 template <int OUT_DT>
-__device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Readback<OUT_DT> &rb, const float (&hv)[2][4], int64_t n_boards,
+__device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Readback<OUT_DT> &rb, const float (&hv)[4], int64_t n_boards,
                                             int64_t tile0, int64_t tstride, int ntiles, int tid, long long *stamps) {
 #define MZ_HSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = (long long)__builtin_readcyclecounter(); } while (0)
     float *hid = reinterpret_cast<float *>(lds);
@@ -625,12 +639,11 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
     heads_prefetch(hd, tid, hr);
     prm[tid] = rb.pv;
     __syncthreads();
-    if (lane < 32) {   // the batch's last tile, from layer_last's D layout: lane -> cell col_cell(lane & 15) of tile j, planes 4 (lane >> 4) + 0..3
-        float *dst = hid + (nb - 4 + (w >> 1)) * 512;
+    {   // the batch's last tile, from layer_last's registers: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3
+        const int q = tid & 255, h = tid >> 8;
+        float *dst = hid + (nb - 4 + (q >> 6)) * 512 + (q & 63);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[(4 * (lane >> 4) + q) * 64 + 32 * (w & 1) + 16 * j + col_cell(lane & 15)] = hv[j][q];
+        for (int k = 0; k < 4; ++k) dst[(4 * h + k) * 64] = hv[k];
     }
     __syncthreads();
     MZ_HSTAMP(21);
@@ -734,7 +747,7 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
 // one 4-board tile through the convolution tower: first layer, three residual blocks, last layer, hidden state stored
 template <int OUT_DT>
 __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const Heads &hd, const uint16_t *__restrict__ x, void *__restrict__ hidden,
-                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[2][4]) {
+                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[4]) {
     Tower tw = tw_;
     if (tw.stamps) tw.stamps += tile * 24;   // this tile's row of the diagnostics array
     const uint32_t vm = halo_mask(tid & 31);
@@ -804,7 +817,7 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
         const bool heads_now = hd.policy != nullptr && (in_batch == 3 || (tile + gridDim.x) * TILE_BOARDS >= n_boards);
         void *hidden = karg<void *>(ka, offsetof(KArgs, hidden));
         Readback<OUT_DT> rb;
-        float hv[2][4];
+        float hv[4];
         tower_tile<OUT_DT>(lds, tw, hd, karg<const uint16_t *>(ka, offsetof(KArgs, x)), hidden, n_boards, tile, tid, rb, heads_now ? in_batch : -1, gridDim.x, hv);
         ++in_batch;
         if (heads_now) {

@@ -142,6 +142,18 @@ def _pack_stages(w, rows):
     return torch.gather(st, 2, idx.view(1, rows, 4, 1).expand(36, rows, 4, 8))
 
 
+def _pack_last(w):
+    """last conv weight (8, 128, 3, 3) -> (4 quarters, 80 rows, 4 slots, 8): the nine taps sit in the GEMM's M dimension, row =
+    tap * 8 + plane (72 real rows, padded to five 16-row MFMA tiles); 64-byte rows with the chunk swizzle of _pack_stages."""
+    dev = w.device
+    rows = torch.zeros((80, 128), dtype=w.dtype, device=dev)
+    rows[:72] = w.permute(2, 3, 0, 1).reshape(72, 128)                       # (ky, kx, plane, ci) -> row = (ky * 3 + kx) * 8 + plane
+    st = rows.reshape(80, 4, 4, 8).permute(1, 0, 2, 3)                       # (quarter, row, chunk, 8)
+    key = torch.tensor(_PERM, device=dev)[(torch.arange(80, device=dev) >> 2) & 3]
+    idx = torch.arange(4, device=dev).unsqueeze(0) ^ key.unsqueeze(1)        # (80, 4): chunk held by each slot
+    return torch.gather(st, 2, idx.view(1, 80, 4, 1).expand(4, 80, 4, 8)).contiguous()
+
+
 def pack_tower(first, blocks, last, device, cin):
     """Prepack one tower (first conv, three ResidualBlocks, last conv -- network.py:54-68 / :118-128) into the
     bf16 LDS images mz_tower_forward streams (include/muzero_amd.h mz_tower_weights).  Returns a dict of device
@@ -156,7 +168,7 @@ def pack_tower(first, blocks, last, device, cin):
                        torch.zeros(4 * 128 * 32, device=dev)])   # + 4 stages of padding: the stream prefetches past the end
     return dict(w_first=wf.to(bf).contiguous(), b_first=None if first.bias is None else f(first.bias).contiguous(),
                 w_mid=w_mid.to(bf).contiguous(), b_mid=torch.stack([f(c.bias) for c in convs]).contiguous(),
-                w_last=_pack_stages(f(last.weight), 16).to(bf).contiguous(),
+                w_last=_pack_last(f(last.weight)).to(bf).contiguous(),
                 b_last=None if last.bias is None else f(last.bias).contiguous(), cin=int(cin))
 
 
