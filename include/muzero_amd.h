@@ -257,14 +257,21 @@ typedef struct mz_replay {
     int32_t window, max_moves;
 } mz_replay;
 
+/* element type of the root visit counts in a trajectory record */
+#define MZ_VIS_I32 0 /* int32, -1 = not a root child (what mz_mcts_root_stats writes) */
+#define MZ_VIS_U16 1 /* uint16, 0 = unvisited or not a root child */
+#define MZ_VIS_U8 2  /* uint8,  0 = unvisited or not a root child (searches of at most 255 simulations) */
+
 /* ReplayBuffer.save_game (utilities.py:56-63) for n games at once: game i of a step-major batch of
  * trajectories (the layout the self-play engine records: hist_* [t * stride + i], t = 0..max_moves;
- * actions/rewards/root_values [t * stride + i]; visits [(t * stride + i) * 65 + a], -1 = not a root
- * child) is written to slot (slot0 + i) mod window.  length: per-game (nullable) else length_all.
- * Game.store_search_statistics' normalisation (reversi.py:292-299) happens here. */
+ * actions/rewards/root_values [t * stride + i]; visits [(t * stride + i) * 65 + a] of visits_dtype: a child that was
+ * never visited and an action that is no root child both normalise to 0, so the narrow types lose nothing here)
+ * is written to slot (slot0 + i) mod window.  length: per-game (nullable) else length_all (values are clamped to
+ * [0, max_moves]).  Game.store_search_statistics' normalisation (reversi.py:292-299) happens here. */
 int mz_replay_save(const mz_replay *rb, int32_t slot0, const uint64_t *hist_white, const uint64_t *hist_black,
-                   const uint8_t *actions, const int8_t *rewards, const int32_t *visits, const float *root_values,
-                   const int32_t *length, int32_t length_all, int64_t stride, int32_t n, void *stream);
+                   const uint8_t *actions, const int8_t *rewards, const void *visits, int32_t visits_dtype,
+                   const float *root_values, const int32_t *length, int32_t length_all, int64_t stride, int32_t n,
+                   void *stream);
 
 /* ReplayBuffer.sample_batch (utilities.py:72-99) for `batch` already-drawn (slot, position) pairs
  * (the draws stay with the caller: random.sample / random.randint, utilities.py:76,104), K =

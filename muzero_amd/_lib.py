@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(HERE, "lib", "libmuz
 
 MZ_F32, MZ_BF16, MZ_F16 = 0, 1, 2
 ST_OK, ST_ILLEGAL, ST_DONE = 0, 1, 2
+VIS_I32, VIS_U16, VIS_U8 = 0, 1, 2
 
 
 class MzError(RuntimeError):
@@ -92,7 +93,7 @@ SIGNATURES = {
                   _p, _p, _p],
     "mz_search_noalloc": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32,
                           _p, _p, _p],
-    "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
+    "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
 }
 for _name, _args in SIGNATURES.items():

@@ -17,8 +17,9 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 __device__ __forceinline__ unsigned encode_rows(int a) { return a >= 64 ? 0xFFu : ((1u << (a >> 3)) | (1u << (a & 7))); }
 
 // ---- save: step-major trajectories -> game-major window slots ------------------------------------
+template <class V>
 __global__ void __launch_bounds__(64) k_replay_save(mz_replay rb, int slot0, const uint64_t *hw, const uint64_t *hb,
-                                                    const uint8_t *actions, const int8_t *rewards, const int32_t *visits,
+                                                    const uint8_t *actions, const int8_t *rewards, const V *visits,
                                                     const float *root_values, const int32_t *length, int length_all, int64_t stride) {
     const int g = blockIdx.x, lane = threadIdx.x;
     const int T = rb.max_moves;
@@ -44,8 +45,8 @@ __global__ void __launch_bounds__(64) k_replay_save(mz_replay rb, int slot0, con
             if (lane == 0) dst[64] = 0.0f;
             continue;
         }
-        const int32_t *v = visits + ((int64_t)t * stride + g) * MZ_ACTIONS;
-        const int n = v[lane], n64 = v[64];
+        const V *v = visits + ((int64_t)t * stride + g) * MZ_ACTIONS;
+        const int n = (int)v[lane], n64 = (int)v[64];
         const int sum = wave_sum_i32(n > 0 ? n : 0) + (n64 > 0 ? n64 : 0);
         const double ds = (double)sum;
         dst[lane] = (n > 0 && sum > 0) ? (float)((double)n / ds) : 0.0f;
@@ -115,8 +116,8 @@ static int check_replay(const char *who, const mz_replay *rb) {
 }
 
 extern "C" int mz_replay_save(const mz_replay *rb, int32_t slot0, const uint64_t *hist_white, const uint64_t *hist_black,
-                              const uint8_t *actions, const int8_t *rewards, const int32_t *visits, const float *root_values,
-                              const int32_t *length, int32_t length_all, int64_t stride, int32_t n, void *stream) {
+                              const uint8_t *actions, const int8_t *rewards, const void *visits, int32_t visits_dtype,
+                              const float *root_values, const int32_t *length, int32_t length_all, int64_t stride, int32_t n, void *stream) {
     if (int rc = check_replay("mz_replay_save", rb)) return rc;
     MZ_REQUIRE(n >= 0 && n <= rb->window, "mz_replay_save: n %d outside [0, window %d]", n, rb->window);
     if (n == 0) return MZ_OK;
@@ -124,8 +125,14 @@ extern "C" int mz_replay_save(const mz_replay *rb, int32_t slot0, const uint64_t
     MZ_REQUIRE(hist_white && hist_black && actions && rewards && visits && root_values, "mz_replay_save: null pointer");
     MZ_REQUIRE(stride >= n, "mz_replay_save: stride < n");
     MZ_REQUIRE(length || (length_all >= 0 && length_all <= rb->max_moves), "mz_replay_save: length_all out of range");
-    hipLaunchKernelGGL(k_replay_save, dim3(n), dim3(64), 0, (hipStream_t)stream, *rb, (int)slot0, hist_white, hist_black, actions, rewards,
-                       visits, root_values, length, (int)length_all, stride);
+    MZ_REQUIRE(visits_dtype == MZ_VIS_I32 || visits_dtype == MZ_VIS_U16 || visits_dtype == MZ_VIS_U8, "mz_replay_save: bad visits_dtype %d", visits_dtype);
+#define MZ_SAVE(V)                                                                                                                     \
+    hipLaunchKernelGGL(k_replay_save<V>, dim3(n), dim3(64), 0, (hipStream_t)stream, *rb, (int)slot0, hist_white, hist_black, actions, rewards, \
+                       (const V *)visits, root_values, length, (int)length_all, stride)
+    if (visits_dtype == MZ_VIS_I32) MZ_SAVE(int32_t);
+    else if (visits_dtype == MZ_VIS_U16) MZ_SAVE(uint16_t);
+    else MZ_SAVE(uint8_t);
+#undef MZ_SAVE
     MZ_LAUNCH_CHECK("k_replay_save");
     return MZ_OK;
 }

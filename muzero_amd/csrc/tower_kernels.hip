@@ -414,8 +414,6 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
 }
 
 struct HeadRegs { bf16x8 a1[4], a2[4]; };   // this wave's weight (A) fragments of the two Linear layers, one per k-step of 32 inputs
-__device__ __forceinline__ float pair_lo(uint32_t v) { return __uint_as_float(v << 16); }
-__device__ __forceinline__ float pair_hi(uint32_t v) { return __uint_as_float(v & 0xFFFF0000u); }
 
 // every global read of the heads' weights, issued at the start of heads_batch.
 // Linear weights are bf16 [out][in] row-major (nn.Linear's own layout): wave w owns output rows 16 w .. 16 w + 15, and

@@ -5,8 +5,8 @@ actor while the trainer samples from it (main.py:26-39, 55-63, 201-227).  Here e
 torch.distributed job (RCCL on the GPUs; none needed for one GPU) alternates, per generation:
 
   1. self-play: `games_per_rank` lock-step games on the rank's own game-id block (no collective);
-  2. trajectory gather: one all_gather of the fixed-size game records (shard.gather_game_records) so
-     every rank's replay window holds the same games in the same (game-id) order;
+  2. trajectory gather: one all_gather_into_tensor per record field (shard.gather_game_records; 5.2 KB per game with
+     uint8 visit counts) so every rank's replay window holds the same games in the same (game-id) order;
   3. training: `train_steps` x (sample_batch on the rank's shard of the global batch ->
      update_weights with ONE flat-bucket gradient all-reduce);
   4. publish: the new weights are copied in place into the rank's InferenceEngine (the parameter
@@ -55,8 +55,8 @@ class MuZeroLoop:
     def generation(self, train_steps):
         """one self-play round + `train_steps` updates; returns the losses of this generation"""
         rec = self.selfplay.play_games()
-        full = gather_game_records(rec, self.group) if self.world > 1 else rec
-        self.replay.save_games(full, lengths=rec.length)
+        for part in gather_game_records(rec, self.group):   # one dict per rank, in game-id order (this rank's own records when alone)
+            self.replay.save_games(part, lengths=rec.length)
         out = []
         if self.replay.ready():
             K = config.num_unroll_steps

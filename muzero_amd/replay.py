@@ -61,9 +61,16 @@ class ReplayBuffer:
         """n games at once from step-major trajectory tensors (selfplay.GameRecords or the dict
         shard.gather_game_records returns).  lengths: per-game int32 tensor / list, default rec.length."""
         get = (lambda k: rec[k]) if isinstance(rec, dict) else (lambda k: getattr(rec, k))
-        hw, hb, acts, rews, visits, rv = (get(k).contiguous() for k in ("hist_white", "hist_black", "actions", "rewards",
-                                                                        "visits", "root_values"))
+        hw, hb, acts, rews, visits, rv = (get(k) for k in ("hist_white", "hist_black", "actions", "rewards", "visits", "root_values"))
         n = acts.shape[1]
+        # step-major (T, n, ...) batches; a trimmed view of a wider gather buffer is fine as long as every field shares
+        # the row stride (mz_replay_save takes it): only a view that is not row-contiguous gets copied
+        stride = hw.stride(0) if hw.dim() == 2 and hw.stride(1) == 1 else None
+        ok = stride is not None and all(t.stride(0) == stride * (65 if t.dim() == 3 else 1) and t.stride(1) == (65 if t.dim() == 3 else 1)
+                                        for t in (hb, acts, rews, visits, rv)) and (visits.dim() == 3 and visits.stride(2) == 1)
+        if not ok:
+            hw, hb, acts, rews, visits, rv = (t.contiguous() for t in (hw, hb, acts, rews, visits, rv))
+            stride = hw.shape[1]
         if hw.shape[0] != self.max_moves + 1 or acts.shape[0] != self.max_moves:
             raise L.MzError("records are for max_moves=%d, buffer for %d" % (acts.shape[0], self.max_moves))
         if lengths is None:
@@ -77,8 +84,14 @@ class ReplayBuffer:
         if len(host) != n or any(ln < 0 or ln > self.max_moves for ln in host):
             raise L.MzError("game lengths must be %d values in [0, %d]" % (n, self.max_moves))
         slot0 = self._claim(n)
-        L.call("mz_replay_save", L.C.byref(self._rb), slot0, L.dptr(hw), L.dptr(hb), L.dptr(acts), L.dptr(rews), L.dptr(visits),
-               L.dptr(rv), L.dptr(per_game), 0 if per_game is not None else host[0], hw.shape[1], n, L.current_stream())
+        vis_dt = {torch.int32: L.VIS_I32, torch.int16: L.VIS_U16, torch.uint16: L.VIS_U16, torch.uint8: L.VIS_U8}.get(visits.dtype)
+        if vis_dt is None:
+            raise L.MzError("visits must be int32 (-1 = not a root child), int16/uint16 or uint8 counts, got %s" % visits.dtype)
+        _ptr = lambda t: L.C.c_void_p(t.data_ptr())  # noqa: E731  (strided views: checked above; L.dptr insists on contiguous tensors)
+        if not all(t.is_cuda for t in (hw, hb, acts, rews, visits, rv)):
+            raise L.MzError("muzero_amd kernels need device tensors (no CPU fallback)")
+        L.call("mz_replay_save", L.C.byref(self._rb), slot0, _ptr(hw), _ptr(hb), _ptr(acts), _ptr(rews), _ptr(visits), vis_dt,
+               _ptr(rv), L.dptr(per_game), 0 if per_game is not None else host[0], stride, n, L.current_stream())
         for i, ln in enumerate(host):
             self._lengths[(slot0 + i) % self.window_size] = ln
         self.counter += sum(host)

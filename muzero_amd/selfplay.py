@@ -47,15 +47,20 @@ class NetworkAdapter:
 class GameRecords:
     """Trajectories of n games (device tensors, step-major) -- the fields of reference ``Game``
     (reversi.py:257-266): state_history, action_history, rewards, child_visits (as raw visit
-    counts, -1 = not a root child), root_values."""
+    counts, 0 for an action that is no root child), root_values."""
 
-    def __init__(self, n, device, max_moves):
+    def __init__(self, n, device, max_moves, max_visits=None):
+        """max_visits: the largest count a root child can reach (= simulations per search).  Counts are kept in the
+        narrowest type that holds it -- uint8 up to 255 simulations, int16 up to 32,767, else int32 -- with 0 for an action
+        that is no root child (it normalises to 0 either way, reversi.py:292-298): 65 B instead of 260 B per move, which is
+        most of a trajectory record (5.2 KB per game on the wire at S <= 255)."""
         self.n, self.max_moves = n, max_moves
+        vis_dt = torch.int32 if max_visits is None else (torch.uint8 if max_visits <= 255 else torch.int16 if max_visits <= 32767 else torch.int32)
         self.hist_white = torch.zeros((max_moves + 1, n), dtype=torch.int64, device=device)
         self.hist_black = torch.zeros((max_moves + 1, n), dtype=torch.int64, device=device)
         self.actions = torch.zeros((max_moves, n), dtype=torch.uint8, device=device)
         self.rewards = torch.zeros((max_moves, n), dtype=torch.int8, device=device)
-        self.visits = torch.zeros((max_moves, n, 65), dtype=torch.int32, device=device)
+        self.visits = torch.zeros((max_moves, n, 65), dtype=vis_dt, device=device)
         self.root_values = torch.zeros((max_moves, n), dtype=torch.float32, device=device)
         self.length = 0
 
@@ -157,7 +162,7 @@ class SelfPlayEngine:
         """Play n games from the opening. noise: optional (moves, n, 65) f64 by action; u: optional
         (moves, n) f64 uniforms for the sampled moves (both default to the engine's generator)."""
         T = int(max_moves if max_moves is not None else self.cfg.max_moves)
-        rec = GameRecords(self.n, self.device, T)
+        rec = GameRecords(self.n, self.device, T, max_visits=self.S)
         env = self.env
         env.reset()
         bad = torch.zeros(self.n, dtype=torch.bool, device=self.device)
@@ -175,7 +180,7 @@ class SelfPlayEngine:
             err |= self.mcts.meta()[:, META_ERROR] != 0   # root_init clears the flag, so collect it per move
             rec.actions[t].copy_(action)
             rec.rewards[t].copy_(reward)
-            rec.visits[t].copy_(visits)
+            rec.visits[t].copy_(visits.clamp_min(0))   # -1 (not a root child) -> 0; narrowed to the record's count type
             rec.root_values[t].copy_(root_value)
             rec.hist_white[t + 1].copy_(env.white)
             rec.hist_black[t + 1].copy_(env.black)

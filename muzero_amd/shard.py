@@ -32,29 +32,46 @@ def max_over_ranks(seconds, device="cpu", group=None):
 
 RECORD_FIELDS = ("hist_white", "hist_black", "actions", "rewards", "visits", "root_values")
 
+_GATHER_BUFFERS = {}   # (field, shape, dtype, device) -> preallocated (world, T, n, ...) receive buffer, reused every generation
+
+
+def record_bytes_per_game(rec):
+    """bytes one game contributes to the trajectory gather (SURVEY 8e budgets 4-8 KB)"""
+    n = rec.actions.shape[1]
+    return sum(getattr(rec, k).numel() * getattr(rec, k).element_size() for k in RECORD_FIELDS) // n
+
 
 def gather_game_records(rec, group=None):
-    """all_gather the step-major trajectory tensors of every rank along the game axis (dim 1).
+    """Bring the step-major trajectory tensors of every rank together: ONE all_gather_into_tensor per field, straight into
+    a preallocated (world, T, n, ...) buffer -- no list of parts, no pad, no concatenation copy.
 
-    `rec` is a GameRecords (or any object with RECORD_FIELDS tensors shaped (T, n_local, ...)).
-    Ranks may hold different n_local (game_block remainders): shorter shards are padded to the
-    longest for the collective and trimmed afterwards.  Returns {field: tensor (T, total, ...)} in
-    rank order = game-id order."""
+    `rec` is a GameRecords (or any object with RECORD_FIELDS tensors shaped (T, n_local, ...)).  Returns a list with one
+    {field: tensor (T, n_r, ...)} per rank, in rank order = game-id order (views of the receive buffers; they stay valid
+    until the next gather).  ReplayBuffer.save_games takes them one by one (mz_replay_save reads step-major batches with a
+    stride, so no re-layout is needed).  Ranks may hold different n_local (game_block remainders): then every rank pads
+    to the longest shard for the collective (one copy on the short ranks only) and the views are trimmed."""
     fields = {k: getattr(rec, k) for k in RECORD_FIELDS}
-    if not (dist.is_available() and dist.is_initialized()):
-        return fields
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [fields]
     world = dist.get_world_size(group)
+    dev = fields["actions"].device
     n_local = fields["actions"].shape[1]
-    counts = [torch.zeros(1, dtype=torch.int64, device=fields["actions"].device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([n_local], dtype=torch.int64, device=fields["actions"].device), group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, torch.tensor([n_local], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c) for c in counts.tolist()]
     n_max = max(counts)
-    out = {}
+    out = [dict() for _ in range(world)]
     for k, t in fields.items():
         if n_local < n_max:
-            pad = torch.zeros((t.shape[0], n_max - n_local) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
-            t = torch.cat([t, pad], 1)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t.contiguous(), group=group)
-        out[k] = torch.cat([p[:, :c] for p, c in zip(parts, counts)], 1)
+            pad = torch.zeros((t.shape[0], n_max) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            pad[:, :n_local] = t
+            t = pad
+        t = t.contiguous()
+        key = (k, tuple(t.shape), t.dtype, t.device, world)
+        buf = _GATHER_BUFFERS.get(key)
+        if buf is None:
+            buf = _GATHER_BUFFERS[key] = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf.view((world * t.shape[0],) + tuple(t.shape[1:])), t, group=group)   # rank-major along dim 0
+        for r in range(world):
+            out[r][k] = buf[r] if counts[r] == n_max else buf[r][:, :counts[r]]
     return out

@@ -142,3 +142,27 @@ def test_selfplay_records_feed_the_buffer():
     for a, b in zip(out, want):
         assert (C(a).view(np.uint32) == b.view(np.uint32)).all()
     assert HashNetTorch is not None
+
+
+@pytest.mark.parametrize("dt", [torch.uint8, torch.int16])
+def test_narrow_visit_counts_and_strided_views(golden_dir, dt):
+    """trajectory records with uint8 / int16 visit counts (0 for non-children, as GameRecords keeps them) build the very
+    same batches as the int32 (-1) form; and a trimmed VIEW of a wider gather buffer is saved without a re-layout"""
+    from muzero_amd.replay import ReplayBuffer
+    G = np.load(os.path.join(golden_dir, "replay.npz"))
+    rb = ReplayBuffer(window_size=int(G["window_size"]), batch_size=int(G["batch_size"]))
+    for ids in ([0, 1, 2], [3, 4, 5, 6, 7]):
+        part = step_major(G, ids)
+        part["visits"] = part["visits"].clamp_min(0).to(dt)
+        if len(ids) == 5:   # as shard.gather_game_records hands a short rank's shard over: a (T, 5) view of a (T, 9) buffer
+            wide = {k: torch.zeros((v.shape[0], 9) + tuple(v.shape[2:]), dtype=v.dtype, device="cuda") for k, v in part.items()}
+            for k, v in part.items():
+                wide[k][:, :5] = v
+            part = {k: v[:, :5] for k, v in wide.items()}
+            assert not part["visits"].is_contiguous()
+        rb.save_games(part, lengths=G["length"][ids].tolist())
+    check_batches(rb, G, False)
+    with pytest.raises(Exception):
+        bad = step_major(G, [0])
+        bad["visits"] = bad["visits"].float()
+        rb.save_games(bad, lengths=[60])

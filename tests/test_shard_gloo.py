@@ -46,9 +46,15 @@ def _worker(rank, world, port, total, out_dir):
     rec.hist_black = torch.from_numpy(np.tile(e.black.view(np.int64)[None], (61, 1)))
     rec.actions = torch.from_numpy(actions.T.copy())
     rec.rewards = torch.from_numpy(np.tile(last_reward[None], (60, 1)))
-    rec.visits = torch.from_numpy(np.tile(digest.view(np.int64)[None, :, None] % 1000, (60, 1, 65)).astype(np.int32))
+    rec.visits = torch.from_numpy(np.tile(digest.view(np.int64)[None, :, None] % 251, (60, 1, 65)).astype(np.uint8))   # uint8 counts, as the engine records them
     rec.root_values = torch.full((60, n), float(rank))
-    full = gather_game_records(rec)
+    from muzero_amd.shard import record_bytes_per_game
+    assert record_bytes_per_game(rec) <= 8 * 1024   # 4-8 KB per game on the wire
+    parts = gather_game_records(rec)     # one {field: (T, n_r, ...)} per rank, in game-id order
+    assert len(parts) == world and [p["actions"].shape[1] for p in parts] == [game_block(total, r, world)[1] for r in range(world)]
+    full = {k: torch.cat([p[k] for p in parts], 1) for k in parts[0]}
+    again = gather_game_records(rec)     # the receive buffers are reused
+    assert again[0]["visits"].data_ptr() == parts[0]["visits"].data_ptr()
     t = max_over_ranks(1.0 + rank)
     dist.barrier()
     if rank == 0:
@@ -70,6 +76,6 @@ def test_two_rank_sharding_and_gather(tmp_path):
     assert (got["actions"] == actions.T).all()
     assert (got["hist_white"][0].view(np.uint64) == e.white).all() and (got["hist_black"][60].view(np.uint64) == e.black).all()
     assert (got["rewards"][0] == last_reward).all()
-    assert (got["visits"][0, :, 0] == (digest.view(np.int64) % 1000).astype(np.int32)).all()
+    assert got["visits"].dtype == np.uint8 and (got["visits"][0, :, 0] == (digest.view(np.int64) % 251).astype(np.uint8)).all()
     assert (got["root_values"][0, :151] == 0).all() and (got["root_values"][0, 151:] == 1).all()
     assert float(got["t"]) == 2.0
