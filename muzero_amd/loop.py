@@ -25,13 +25,17 @@ from . import config
 from .network import InferenceEngine, Network
 from .replay import ReplayBuffer
 from .selfplay import SelfPlayEngine
-from .shard import gather_game_records
+from .shard import gather_game_records, owner_of_global_game
 from . import train as T
 
 
 class MuZeroLoop:
     def __init__(self, games_per_rank, device="cuda", infer_dtype=torch.bfloat16, num_simulations=None, window_size=None,
-                 batch_size=None, seed=1261, use_graph=True, group=None):
+                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated"):
+        """replay_mode "replicated": trajectories are all_gathered and every rank holds the whole window (what
+        BASELINE configs[3] describes); "sharded": no gather at all -- every rank keeps only the games it played (1/N of the
+        window), all ranks make the same global draws and each trains on the draws that hit its own games, with the
+        gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw."""
         self.group = group
         self.world = dist.get_world_size(group) if T._dist_on(group) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -49,24 +53,47 @@ class MuZeroLoop:
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)
         if self.batch_size % self.world:
             raise ValueError("global batch %d is not divisible by %d ranks" % (self.batch_size, self.world))
-        self.replay = ReplayBuffer(self.device, window_size=window_size, batch_size=self.batch_size)
+        if replay_mode not in ("replicated", "sharded"):
+            raise ValueError("replay_mode must be 'replicated' or 'sharded'")
+        self.replay_mode = replay_mode
+        self.games_per_rank = int(games_per_rank)
+        window = int(window_size if window_size is not None else config.window_size)
+        if replay_mode == "sharded":
+            if window % (self.games_per_rank * self.world):
+                raise ValueError("a sharded window of %d games must hold whole generations of %d x %d games" % (window, self.games_per_rank, self.world))
+            window //= self.world
+        self.replay = ReplayBuffer(self.device, window_size=window, batch_size=self.batch_size if replay_mode == "replicated" else 1)
         self.losses = []
 
     def generation(self, train_steps):
         """one self-play round + `train_steps` updates; returns the losses of this generation"""
         rec = self.selfplay.play_games()
-        for part in gather_game_records(rec, self.group):   # one dict per rank, in game-id order (this rank's own records when alone)
-            self.replay.save_games(part, lengths=rec.length)
+        K = config.num_unroll_steps
         out = []
-        if self.replay.ready():
-            K = config.num_unroll_steps
+        if self.replay_mode == "replicated":
+            for part in gather_game_records(rec, self.group):   # one dict per rank, in game-id order (this rank's own records when alone)
+                self.replay.save_games(part, lengths=rec.length)
+            n_global = self.replay.buffer_size
+        else:
+            self.replay.save_games(rec)                          # no collective: the window is sharded by game id
+            n_global = self.replay.buffer_size * self.world
+        if n_global >= self.batch_size:                          # ReplayBuffer.ready(), utilities.py:65-69, on the global window
             shard = self.batch_size // self.world
             for _ in range(train_steps):
-                idx = random.sample(range(self.replay.buffer_size), self.batch_size)   # utilities.py:76
-                pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
-                sl = slice(self.rank * shard, (self.rank + 1) * shard)
-                batch = self.replay.sample_batch(K, idx[sl], pos[sl])
-                out.append(T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group))
+                idx = random.sample(range(n_global), self.batch_size)                      # utilities.py:76 (same draws on every rank)
+                if self.replay_mode == "replicated":
+                    pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
+                    sl = slice(self.rank * shard, (self.rank + 1) * shard)
+                    batch, scale = self.replay.sample_batch(K, idx[sl], pos[sl]), 1.0
+                else:
+                    # every game of this engine lasts exactly max_moves moves (selfplay.py), so all ranks can make the
+                    # reference's position draw (utilities.py:104) for games they do not hold
+                    pos = [random.randint(0, rec.length - K) for _ in idx]
+                    mine = [(li, p) for (r, li), p in ((owner_of_global_game(i, self.games_per_rank, self.world), p) for i, p in zip(idx, pos))
+                            if r == self.rank]
+                    batch = self.replay.sample_batch(K, [li for li, _ in mine], [p for _, p in mine]) if mine else None
+                    scale = len(mine) * self.world / self.batch_size
+                out.append(T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group, loss_scale=scale))
             self.storage.save_network(self.network.state_dict())
             self.infer.load_weights(self.storage.get_network())
         self.losses.extend(out)

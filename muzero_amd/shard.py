@@ -30,6 +30,16 @@ def max_over_ranks(seconds, device="cpu", group=None):
     return float(t.item())
 
 
+def owner_of_global_game(i, games_per_rank, world):
+    """Sharded replay window: every rank keeps only the games it played; the GLOBAL window (what one process would hold)
+    lists, per generation, rank 0's games, then rank 1's, ... (game-id order).  Global FIFO index i (0 = oldest) ->
+    (owning rank, index in that rank's local FIFO).  All ranks hold the same number of generations."""
+    per_gen = int(games_per_rank) * int(world)
+    gen, within = divmod(int(i), per_gen)
+    rank, j = divmod(within, int(games_per_rank))
+    return rank, gen * int(games_per_rank) + j
+
+
 RECORD_FIELDS = ("hist_white", "hist_black", "actions", "rewards", "visits", "root_values")
 
 _GATHER_BUFFERS = {}   # (field, shape, dtype, device) -> preallocated (world, T, n, ...) receive buffer, reused every generation

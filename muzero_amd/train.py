@@ -94,23 +94,33 @@ def muzero_loss(network, batch):
     return p_loss, v_loss
 
 
-def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None):
+def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None, loss_scale=1.0):
     """main.py:230-272.  With `bucket` (FlatGradBucket over network.parameters()) the gradients are
     averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step.
     amp_dtype (e.g. torch.bfloat16): run the forward/backward convolutions under torch.autocast (fp32 master
-    weights, gradients and optimiser state stay fp32); None = the reference's fp32 arithmetic."""
+    weights, gradients and optimiser state stay fp32); None = the reference's fp32 arithmetic.
+    loss_scale: data-parallel ranks with UNEQUAL local batches (sharded replay window) pass b_local * world / B_global, so the
+    mean over ranks of the scaled gradients is the gradient of the mean over the global batch; batch=None = this rank drew
+    no sample this step (it contributes a zero gradient and still joins the all-reduce).  The returned losses are unscaled."""
     if bucket is not None:
         bucket.zero()
     else:
         optimizer.zero_grad()
-    if amp_dtype is not None:
+    if batch is None:
+        if bucket is None:
+            raise RuntimeError("an empty local batch needs a FlatGradBucket (the zero gradient must exist to be all-reduced)")
         dev = next(network.parameters()).device
-        with torch.autocast(dev.type, dtype=amp_dtype):
-            p_loss, v_loss = muzero_loss(network, batch)
-        p_loss, v_loss = p_loss.float(), v_loss.float()
+        p_loss = v_loss = torch.zeros((), device=dev)
     else:
-        p_loss, v_loss = muzero_loss(network, batch)
-    (p_loss + v_loss).backward()
+        if amp_dtype is not None:
+            dev = next(network.parameters()).device
+            with torch.autocast(dev.type, dtype=amp_dtype):
+                p_loss, v_loss = muzero_loss(network, batch)
+            p_loss, v_loss = p_loss.float(), v_loss.float()
+        else:
+            p_loss, v_loss = muzero_loss(network, batch)
+        total = p_loss + v_loss
+        (total if loss_scale == 1.0 else total * float(loss_scale)).backward()
     if bucket is not None:
         bucket.all_reduce_mean(group)
     elif _dist_on(group):

@@ -29,3 +29,24 @@ def test_two_generations():
         assert loop.network.steps == 6
     finally:
         config.num_unroll_steps = old
+
+
+def test_sharded_window_equals_replicated_on_one_rank():
+    """replay_mode="sharded" (no trajectory gather, local batches weighted in the all-reduce) makes the same draws and the
+    same updates as the replicated window; with one rank the two must agree exactly"""
+    from muzero_amd import config
+    from muzero_amd.loop import MuZeroLoop
+    old = config.num_unroll_steps
+    config.num_unroll_steps = 3
+    try:
+        runs = []
+        for mode in ("replicated", "sharded"):
+            loop = MuZeroLoop(32, num_simulations=4, window_size=64, batch_size=16, infer_dtype=torch.bfloat16, replay_mode=mode, use_graph=False)
+            losses = loop.generation(2) + loop.generation(2) + loop.generation(1)   # the third generation evicts the first
+            runs.append(([float(p) for p, _ in losses], [p.detach().clone() for p in loop.network.parameters()]))
+        # same games, same draws, same arithmetic; MIOpen's backward may sum in a different order from run to run
+        assert len(runs[0][0]) == 5 and np.allclose(runs[0][0], runs[1][0], rtol=1e-4)
+        for a, b in zip(runs[0][1], runs[1][1]):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-6)
+    finally:
+        config.num_unroll_steps = old

@@ -154,3 +154,56 @@ def test_two_rank_gradient_all_reduce(tmp_path):
         T.update_weights(opt, net, batch(b))
     for k, v in net.state_dict().items():
         assert torch.allclose(v, r0[k], rtol=1e-4, atol=1e-6), k
+
+
+def _worker_unequal(rank, world, port, out_dir):
+    """sharded replay window: rank 0 drew 3 of the 4 samples, rank 1 one; next step rank 1 drew none at all"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    torch.manual_seed(1261)
+    net = Network()
+    opt = T.make_optimizer(net)
+    bucket = T.FlatGradBucket(net.parameters())
+    T.LOG = None
+    for b, splits in ((0, (slice(0, 3), slice(3, 4))), (1, (slice(0, 4), slice(4, 4)))):
+        img, act, tv, tp = batch(b)
+        sl = splits[rank]
+        k = sl.stop - sl.start
+        local = (img[sl], act[:, sl], tv[:, sl], tp[:, sl]) if k else None
+        T.update_weights(opt, net, local, bucket, loss_scale=k * world / 4)
+    torch.save(net.state_dict(), os.path.join(out_dir, "u%d.pth" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_local_batches_weighted_all_reduce(tmp_path):
+    """loss_scale = b_local * world / B makes 3 + 1 (and 4 + 0) samples on two ranks train like the 4-sample batch on one"""
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    from muzero_amd.shard import owner_of_global_game
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_unequal, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "u0.pth"), weights_only=True)
+    r1 = torch.load(os.path.join(str(tmp_path), "u1.pth"), weights_only=True)
+    torch.manual_seed(1261)
+    net = Network()
+    opt = T.make_optimizer(net)
+    log, T.LOG = T.LOG, None
+    for b in (0, 1):
+        T.update_weights(opt, net, batch(b))
+    T.LOG = log
+    for k, v in net.state_dict().items():
+        assert torch.equal(r0[k], r1[k]), k
+        assert torch.allclose(v, r0[k], rtol=1e-4, atol=1e-6), k
+    # the global FIFO of a sharded window: per generation rank 0's games, then rank 1's, ...
+    n, world = 3, 2
+    order = [owner_of_global_game(i, n, world) for i in range(12)]
+    assert order == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (0, 3), (0, 4), (0, 5), (1, 3), (1, 4), (1, 5)]
