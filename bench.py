@@ -160,7 +160,8 @@ def bench_env(args, device):
         ms_big = step_kernel_ms(eb, big, 1 << 24, 1)
         g2 = big * ENV_BYTES_PER_STEP / (ms_big * 1e-3) / 1e9
         roof_big = {"kernel": "k_env_step", "games": big, "bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": g2 / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": ms_big * 1e3, "env_steps_per_sec": big / (ms_big * 1e-3),
+                    "frac": g2 / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step_hbm"), "algorithmic_bytes_per_launch": big * ENV_BYTES_PER_STEP,
+                    "us_per_launch": ms_big * 1e3, "env_steps_per_sec": big / (ms_big * 1e-3),
                     "working_set_bytes": big * 21, "note": "state exceeds L2 + Infinity Cache: served from HBM"}
         del eb
     isa = kernel_isa("k_env_step")
