@@ -66,9 +66,10 @@ def _ref_tower(x, first, blocks, last):
     return q(torch.relu(conv(y, last)))
 
 
-@pytest.mark.parametrize("n", [4096, 203, 1])
+@pytest.mark.parametrize("n", [4096, 6001, 203, 1])
 def test_hip_tower_vs_torch_fp32_reference(n):
-    """mz_tower_forward (both towers) through the C ABI against the fp32 reference; ragged n covers partial tiles"""
+    """mz_tower_forward (both towers) through the C ABI against the fp32 reference; ragged n covers partial tiles, and
+    6001 boards = 1501 tiles gives the persistent workgroups 5 or 6 tiles each (heads batches of 4 + 1 and 4 + 2)"""
     from muzero_amd.network import InferenceEngine, Network
     torch.backends.cudnn.allow_tf32 = False
     torch.manual_seed(1261)
@@ -111,7 +112,7 @@ def test_hip_heads_vs_torch_fp32_reference():
     with torch.no_grad():
         for p in net.prediction.parameters():
             p.mul_(3.0)   # spread the logits: a near-uniform softmax would hide indexing errors
-    for n in (4096, 203, 1):
+    for n in (4096, 6001, 2500, 203, 1):   # 2500 boards: 2 or 3 tiles per workgroup (partial heads batches)
         eng = InferenceEngine(net, n, torch.bfloat16, tower="hip")
         x10 = torch.rand(n, 10, 8, 8, device="cuda").to(torch.bfloat16)
         value, policy, hidden = eng.recurrent(x10)
@@ -184,3 +185,40 @@ def test_hip_tower_f32_hidden_and_argument_checks():
                L.current_stream())
     with pytest.raises(L.MzError):
         eng.recurrent(x10.float())   # the wrapper refuses a non-bf16 input
+
+
+def test_zero_halo_reads_past_the_lds_allocation():
+    """The 3x3 halo has no padding ring: a lane whose shifted position leaves the board reads its fragment at/after the end of
+    the workgroup's LDS allocation, which the hardware returns as zeros (tower_kernels.hip, OFF_Z).  Here every input and every
+    weight is positive and every sum is an exact integer, so an edge or corner cell that picked up ANY non-zero neighbour (a
+    read that wrapped into the activation images instead of returning 0) shows up as an exact mismatch in that cell."""
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(0)
+    net = Network()
+    d = net.dynamics.conv
+    with torch.no_grad():
+        d[0].weight.fill_(1.0)                                   # first layer: every tap of every plane counts 1
+        for blk in (d[2], d[3], d[4]):
+            for conv in (blk.block[0], blk.block[2]):
+                conv.weight.zero_()
+                conv.bias.zero_()
+                conv.weight[:, :, 0, 0] = 0.0
+                idx = torch.arange(128)
+                conv.weight[idx, idx, 1, 1] = 0.5                # centre tap, scaled: the residual block maps x -> x + x/4
+                conv.weight[idx, idx, 0, 2] = 0.25               # and one CORNER tap, so every mid layer exercises the halo too
+        d[5].weight.fill_(1.0 / 64)                              # last layer: every tap again
+    n = 9
+    eng = InferenceEngine(net, n, torch.bfloat16, tower="hip")
+    x10 = torch.ones((n, 10, 8, 8), device="cuda", dtype=torch.bfloat16)
+    x10[1:, :, 3, 4] = 2.0                                       # a few boards with an interior bump as well
+    got = eng._tower_hip("dyn", x10).float()
+    ref = Network().cuda()
+    ref.load_state_dict({k: v.to(torch.bfloat16).float() for k, v in net.state_dict().items()})
+    rd = ref.dynamics.conv
+    with torch.no_grad():
+        want = _ref_tower(x10, rd[0], [rd[2], rd[3], rd[4]], rd[5])
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    # the pattern itself: corners see 4 taps of the first layer, edges 6, the interior 9
+    first = torch.nn.functional.conv2d(x10[:1].float(), torch.ones(1, 10, 3, 3, device="cuda"), padding=1)[0, 0]
+    assert first[0, 0] == 40 and first[0, 3] == 60 and first[3, 3] == 90
+    assert got[0, 0, 0, 0] < got[0, 0, 0, 3] < got[0, 0, 3, 3]
