@@ -310,7 +310,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MZ_BENCH_FORCE_DIST") == "1":   # (forced: the RCCL protocol with a single rank, tests/test_gpu_rccl.py)
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")

@@ -61,7 +61,7 @@ def gather_game_records(rec, group=None):
     stride, so no re-layout is needed).  Ranks may hold different n_local (game_block remainders): then every rank pads
     to the longest shard for the collective (one copy on the short ranks only) and the views are trimmed."""
     fields = {k: getattr(rec, k) for k in RECORD_FIELDS}
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [fields]
     world = dist.get_world_size(group)
     dev = fields["actions"].device
@@ -81,7 +81,9 @@ def gather_game_records(rec, group=None):
         buf = _GATHER_BUFFERS.get(key)
         if buf is None:
             buf = _GATHER_BUFFERS[key] = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf.view((world * t.shape[0],) + tuple(t.shape[1:])), t, group=group)   # rank-major along dim 0
+        # rank-major along dim 0.  The collective sees BYTES: RCCL has no 16-bit integer type (int16 visit counts, S > 255)
+        # and a gather needs none
+        dist.all_gather_into_tensor(buf.view(torch.uint8).view(world * t.shape[0], -1), t.view(torch.uint8).view(t.shape[0], -1), group=group)
         for r in range(world):
             out[r][k] = buf[r] if counts[r] == n_max else buf[r][:, :counts[r]]
     return out
