@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "muzero_amd", "csrc")
 OUT = os.path.join(ROOT, "muzero_amd", "lib", "kernel_isa.json")
 FULL_RATE_CYCLES, HALF_RATE_CYCLES = 2.4, 4.2
 HALF_RATE = re.compile(r"^v_(lshlrev_b64|lshrrev_b64|ashrrev_i64)$")
-KERNELS = {"env_kernels.hip": ["k_env_step"]}
+KERNELS = {"env_kernels.hip": ["k_env_step"], "mcts_kernels.hip": ["k_backup_select"]}   # k_backup_select has loops: its counts are STATIC (bench.py says so)
 
 
 def makefile_flags():
@@ -47,7 +47,7 @@ def census(asm, kernel):
     labels = {m.group(1): i for i, l in enumerate(region) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
     backward = any(labels.get(m.group(1), 1 << 30) < i for i, l in enumerate(region)
                    for m in [re.match(r"^\s+s_cbranch\w*\s+(\.LBB\d+_\d+)", l)] if m)   # a loop would make the static count meaningless
-    return {"valu_instructions": len(valu), "half_rate_64bit_shifts": len(half),
+    return {"valu_instructions": len(valu), "half_rate_64bit_shifts": len(half), "fp64_valu_instructions": sum(o.endswith("_f64") or "_f64_" in o for o in valu),
             "issue_cycles_per_wave": round((len(valu) - len(half)) * FULL_RATE_CYCLES + len(half) * HALF_RATE_CYCLES, 1),
             "salu_instructions": sum(o.startswith("s_") for o in body), "vmem_instructions": sum(o.startswith(("global_", "buffer_", "flat_")) for o in body),
             "has_loop": backward, "cycles_per_full_rate_valu": FULL_RATE_CYCLES, "cycles_per_half_rate_valu": HALF_RATE_CYCLES}
