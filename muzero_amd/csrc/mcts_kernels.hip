@@ -87,21 +87,40 @@ __device__ __forceinline__ MinMax load_minmax(const mz_tree_meta *m) {
 }
 
 // ---- wave primitives ------------------------------------------------------------------------------
+// Reductions on DPP (row operations + row broadcasts, the total read from lane 63): six dependent VALU steps.  __shfl_xor goes
+// through ds_bpermute -- an address computation, an LDS crossbar trip and a wait per step -- and these kernels are bound by
+// VALU issue and by exactly such dependent chains (profiles/r02/tree_experiment_latency.txt).  max / min are exact: same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL, ROW_MASK>(__float_as_int(v), __float_as_int(v))); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL, ROW_MASK>(__double2hiint(v), __double2hiint(v)), dpp_i32<CTRL, ROW_MASK>(__double2loint(v), __double2loint(v)));
+}
+// (a lane outside the row mask keeps its own value: op(v, v) = v)
+#define MZ_WAVE_REDUCE(T, OP, DPP)                                                                                     \
+    v = OP(v, DPP<0xB1, 0xF>(v));  /* quad_perm [1,0,3,2] */                                                           \
+    v = OP(v, DPP<0x4E, 0xF>(v));  /* quad_perm [2,3,0,1] */                                                           \
+    v = OP(v, DPP<0x124, 0xF>(v)); /* row_ror:4 */                                                                     \
+    v = OP(v, DPP<0x128, 0xF>(v)); /* row_ror:8  -> every lane holds its 16-lane row's result */                       \
+    v = OP(v, DPP<0x142, 0xA>(v)); /* row_bcast:15 into rows 1, 3 */                                                   \
+    v = OP(v, DPP<0x143, 0xC>(v)); /* row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's result */
 __device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    MZ_WAVE_REDUCE(float, fmaxf, dpp_f32)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    MZ_WAVE_REDUCE(float, fminf, dpp_f32)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    MZ_WAVE_REDUCE(double, fmax, dpp_f64)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+#undef MZ_WAVE_REDUCE
+// lane `l` of a value, l wave-uniform: v_readlane instead of a ds_bpermute round trip
+__device__ __forceinline__ int lane_i32(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
 __device__ __forceinline__ int hi_bit(uint64_t m) { return 63 - __clzll((long long)m); }
 __device__ __forceinline__ int lo_bit(uint64_t m) { return __ffsll((unsigned long long)m) - 1; }
 __device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -237,7 +256,7 @@ __device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &
         const PbcRec pb = P.pbc[np];
         const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
-        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
+        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)lane_i32((int)r.nc, a);
         if (lane == 0) P.path[tbase + depth] = PathRec{(uint16_t)node, (uint8_t)a, 0};
         ++depth;
         player = -player;  // children belong to the other player (main.py:173)
@@ -439,8 +458,8 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
             vmin = nv;
             vmax = nv;
         }
-        root_n = __shfl(root_n, 0, 64);
-        root_w = __shfl(root_w, 0, 64);
+        root_n = lane_i32(root_n, 0);
+        root_w = __int_as_float(lane_i32(__float_as_int(root_w), 0));
         vmin = wave_min_f32(vmin);
         vmax = wave_max_f32(vmax);
         // MinMaxStats.update (utilities.py:121-123), as tree_backup
@@ -453,18 +472,18 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
     int node = 0, level = 0, a = 0, player = root_player;
     uint32_t np = (uint32_t)root_n;
     for (;;) {
-        if (ok && level < depth && (int)(__shfl(*reinterpret_cast<const int *>(&oldp), level, 64) & 0xFFFF) == node) {
+        if (ok && level < depth && (int)(lane_i32(*reinterpret_cast<const int *>(&oldp), level) & 0xFFFF) == node) {
             // this node's record for the old path's action was rewritten by backup lane level + 1: take it from there
-            const int pa = (__shfl(*reinterpret_cast<const int *>(&oldp), level, 64) >> 16) & 0xFF;
-            const uint32_t pnc = (uint32_t)__shfl((int)b_nc, level + 1, 64);
-            const float pw = __shfl(b_w, level + 1, 64);
+            const int pa = (lane_i32(*reinterpret_cast<const int *>(&oldp), level) >> 16) & 0xFF;
+            const uint32_t pnc = (uint32_t)lane_i32((int)b_nc, level + 1);
+            const float pw = __int_as_float(lane_i32(__float_as_int(b_w), level + 1));
             if (pa == 64) { r64.nc = pnc; r64.w = pw; }
             else if (lane == pa) { r.nc = pnc; r.w = pw; }
         }
         const PbcRec pb = P.pbc[np];
         const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
-        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)__shfl((int)r.nc, a, 64);
+        const uint32_t nc = a == 64 ? r64.nc : (uint32_t)lane_i32((int)r.nc, a);
         if (lane == 0) P.path[tbase + level] = PathRec{(uint16_t)node, (uint8_t)a, 0};
         ++level;
         player = -player;
