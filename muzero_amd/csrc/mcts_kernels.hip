@@ -126,12 +126,22 @@ __device__ __forceinline__ int lo_bit(uint64_t m) { return __ffsll((unsigned lon
 __device__ __forceinline__ float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // ucb_score main.py:153-160 for one child record
+// The kind of the MinMaxStats bounds is the same for every lane of the tree's wave.  Once a backup has updated them they are
+// fp32 tensors, and then every operation of normalize() has a tensor operand: fp32 throughout, no fp64 division.  That is the
+// case of all but the first simulations of a search: the wave-uniform branch below runs it without the generic both-kinds
+// arithmetic (same operations on the same values: same bits).
 __device__ __forceinline__ Mx ucb_score(const ChildRec &r, const PbcRec &pb, const MinMax &mm, bool negamax) {
     const uint32_t n = r.nc & 0xFFFFu;
     const double pb_c = pb.a * (pb.s / (double)(n + 1u));
     const double prior_score = pb_c * r.p;
     Mx value = n == 0 ? mx_py(0.0) : mx_t(r.w / (float)n);  // Node.value() reversi.py:248-251
     if (negamax && n != 0) value.d = -value.d;                // non-default: the child's value seen from the parent's mover
+    if (mm.lo.t && mx_gt(mm.hi, mm.lo)) {
+        // normalize with a tensor minimum: (v - lo) is a tensor, so is (hi - lo), so is the quotient, so is the sum
+        const float lo = mx_f(mm.lo);
+        const float q = (mx_f(value) - lo) / (mx_f(mm.hi) - lo);
+        return mx_t((float)prior_score + q);
+    }
     return mx_add(mx_py(prior_score), mm_normalize(mm, value));
 }
 
@@ -254,7 +264,9 @@ __device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &
         const ChildRec r = recs[lane];
         const ChildRec r64 = recs[64];
         const PbcRec pb = P.pbc[np];
-        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
+        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0);
+        Mx s64 = mx_py(0.0);   // child 64 (pass) is the same record in every lane: scored only where it is a child (never beside placements at a root)
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)r64.nc) != NOT_CHILD) s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
         const uint32_t nc = a == 64 ? r64.nc : (uint32_t)lane_i32((int)r.nc, a);
         if (lane == 0) P.path[tbase + depth] = PathRec{(uint16_t)node, (uint8_t)a, 0};
@@ -481,7 +493,9 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
             else if (lane == pa) { r.nc = pnc; r.w = pw; }
         }
         const PbcRec pb = P.pbc[np];
-        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0), s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
+        const Mx s = ucb_score(r, pb, mm, cfg.negamax != 0);
+        Mx s64 = mx_py(0.0);   // child 64 (pass) is the same record in every lane: scored only where it is a child (never beside placements at a root)
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)r64.nc) != NOT_CHILD) s64 = ucb_score(r64, pb, mm, cfg.negamax != 0);
         a = select_argmax(r.nc != NOT_CHILD, s, r64.nc != NOT_CHILD, s64, lane, tie_lowest);
         const uint32_t nc = a == 64 ? r64.nc : (uint32_t)lane_i32((int)r.nc, a);
         if (lane == 0) P.path[tbase + level] = PathRec{(uint16_t)node, (uint8_t)a, 0};
