@@ -411,8 +411,8 @@ def main():
                                 "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
                                 "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes),
                                 "share_of_step": us * 1e-3 / (dt / args.steps / S * 1e3),
-                                "note": "HBM fraction as SURVEY 8(d) defines it; the kernel is VALU-issue bound at 4 waves per SIMD (the reference's mixed "
-                                        "f64/f32 arithmetic), not latency or bandwidth bound: profiles/r02/tree_experiment_latency.txt",
+                                "note": "HBM fraction as SURVEY 8(d) defines it; under load the kernel is bound by the latency of ~25 scattered 1 KB requests per "
+                                        "tree (waves wait 60 % of their cycles, VALU active 15 %), not by bandwidth: profiles/r02/tree_experiment_latency.txt",
                                 "valu_static": {k: (kernel_isa("k_backup_select") or {}).get(k) for k in
                                                 ("valu_instructions", "fp64_valu_instructions", "salu_instructions", "vmem_instructions", "has_loop")}}
         # ---- the dominant kernel of the timed region: the inference launch (k_tower: conv tower + heads, ~97 % of a
