@@ -48,3 +48,17 @@ if len(hb):
     seg = torch.stack([hb[:, 21] - hb[:, 19], hb[:, 22] - hb[:, 21], hb[:, 23] - hb[:, 22], hb[:, 16] - hb[:, 23], hb[:, 19] - hb[:, 15]], 1)
     print("heads batch (%d batches): staging %.0f | 1x1 convs %.0f | Linear layers %.0f | softmax+out %.0f | (last layer end -> heads start %.0f)"
           % ((len(hb),) + tuple(float(x) for x in seg.mean(0))))
+# spread between CUs: a workgroup's whole run (its first tile's start -> its last tile's end), grouped by XCD (workgroups are dealt
+# round-robin over the 8 XCDs: wg % 8) -- are whole XCDs slow, or single CUs?
+ncu = 256
+if nb >= 2 * ncu and nb % ncu == 0:
+    k = nb // ncu
+    wg_t = (r1.view(k, ncu)[-1] - r0.view(k, ncu)[0]) * 0.01            # us per workgroup
+    cyc = (s[:, 16] - s[:, 0]).view(k, ncu).sum(0)                       # shader cycles per workgroup (sum over its tiles)
+    print("workgroup run time: mean %.1f us, min %.1f, max %.1f; cycles per workgroup: mean %.0f, min %.0f, max %.0f" %
+          (float(wg_t.mean()), float(wg_t.min()), float(wg_t.max()), float(cyc.mean()), float(cyc.min()), float(cyc.max())))
+    for x in range(8):
+        sel = torch.arange(ncu) % 8 == x
+        print("  XCD %d: run time mean %.1f us (min %.1f, max %.1f), cycles mean %.0f, clock %.3f GHz" %
+              (x, float(wg_t[sel].mean()), float(wg_t[sel].min()), float(wg_t[sel].max()), float(cyc[sel].mean()),
+               float((cyc[sel] / wg_t[sel]).mean()) * 1e-3))
