@@ -224,9 +224,16 @@ def bench_train(args, device, rec):
     torch.cuda.synchronize()
     dt_amp = (time.perf_counter() - t0) / iters
     config.num_unroll_steps = 3
+    # arithmetic of one step: K + 1 network passes over B boards (one Representation, K Dynamics: the same tower FLOPs), each
+    # forward + gradient w.r.t. its input + gradient w.r.t. its weights = 3 x the forward FLOPs (heads and loss are < 1 %)
+    flop = 3.0 * (K + 1) * B * TOWER_FLOP
     return {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
             "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss),
-            "bf16_autocast_ms_per_step": dt_amp * 1e3}
+            "bf16_autocast_ms_per_step": dt_amp * 1e3, "algorithmic_flop_per_step": flop,
+            "tflops": flop / dt / 1e12, "frac_of_fp32_matrix_peak": flop / dt / 1e12 / F32_PEAK_TFLOPS,
+            "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
+            "note": "MIOpen convolutions through PyTorch autograd (fp32 as the reference; the autocast figure keeps fp32 master weights): "
+                    "the step is kernel-bound, not launch-bound (DESIGN.md 5); hand-written bf16 backward kernels are the next-list item"}
 
 
 def bench_loop(args, device, dtype):
