@@ -260,7 +260,17 @@ class InferenceEngine:
         L.call("mz_tower_forward", L.C.byref(pk["struct"]), L.dptr(x), L.dptr(hidden), L.MZ_BF16, x.shape[0], L.current_stream())
         return hidden
 
-    def _infer_hip(self, name, x):
+    def output_buffers(self, n=None):
+        """(value, policy, hidden) tensors a caller may pass as `out=` to initial() / recurrent() of the HIP path: a search that
+        consumes each result before asking for the next (selfplay) reuses ONE set instead of taking three fresh tensors per
+        call -- no allocator work in the eager paths, and under graph capture every simulation step writes the same 5 MB
+        instead of S different ones"""
+        n = self.batch if n is None else n
+        return (torch.empty(n, dtype=torch.float32, device=self.device),
+                torch.empty((n, config.action_space_size), dtype=torch.float32, device=self.device),
+                torch.empty((n, HIDDEN_PLANES, 8, 8), dtype=torch.bfloat16, device=self.device))
+
+    def _infer_hip(self, name, x, out=None):
         """tower + prediction heads in one launch (mz_inference_forward) -> (value, policy, hidden)"""
         L = self._L
         pk = self._packs[name]
@@ -268,9 +278,13 @@ class InferenceEngine:
         if x.dtype != torch.bfloat16 or tuple(x.shape[1:]) != (pk["cin"], 8, 8):
             raise L.MzError("HIP tower input must be a bf16 (n,%d,8,8) tensor" % pk["cin"])
         n = x.shape[0]
-        hidden = torch.empty((n, HIDDEN_PLANES, 8, 8), dtype=torch.bfloat16, device=x.device)
-        value = torch.empty(n, dtype=torch.float32, device=x.device)
-        policy = torch.empty((n, config.action_space_size), dtype=torch.float32, device=x.device)
+        if out is None:
+            out = self.output_buffers(n)
+        value, policy, hidden = out
+        if (value.shape != (n,) or policy.shape != (n, config.action_space_size) or hidden.shape != (n, HIDDEN_PLANES, 8, 8) or
+                value.dtype != torch.float32 or policy.dtype != torch.float32 or hidden.dtype != torch.bfloat16 or
+                not (value.is_contiguous() and policy.is_contiguous() and hidden.is_contiguous()) or value.device != x.device):
+            raise L.MzError("out= must be contiguous (value f32 (n,), policy f32 (n,65), hidden bf16 (n,8,8,8)) on the input's device")
         L.call("mz_inference_forward", L.C.byref(pk["struct"]), L.C.byref(self._packs["heads"]["struct"]), L.dptr(x), L.dptr(hidden),
                L.MZ_BF16, L.dptr(value), L.dptr(policy), n, L.current_stream())
         return value, policy, hidden
@@ -333,13 +347,14 @@ class InferenceEngine:
                 hidden.contiguous(memory_format=torch.contiguous_format))
 
     @torch.no_grad()
-    def initial(self, image):
+    def initial(self, image, out=None):
+        """out: see output_buffers() (HIP path only; the MIOpen path returns what PyTorch allocates)"""
         if self.tower == "hip":
-            return self._infer_hip("repr", image.to(self.dtype))
+            return self._infer_hip("repr", image.to(self.dtype), out)
         return self._finish(self._hidden_initial(image.to(self.dtype)))
 
     @torch.no_grad()
-    def recurrent(self, x10):
+    def recurrent(self, x10, out=None):
         if self.tower == "hip":
-            return self._infer_hip("dyn", x10)
+            return self._infer_hip("dyn", x10, out)
         return self._finish(self._hidden_recurrent(x10))

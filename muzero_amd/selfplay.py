@@ -18,6 +18,8 @@ The S-loop body (network + fused tree kernel) is captured once into a hipGraph a
 Randomness (Dirichlet noise, sampling uniforms) comes from a torch generator on the device, or is
 supplied by the caller (parity tests replay the reference's own draws).
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -86,6 +88,7 @@ class SelfPlayEngine:
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self._graph = None
+        self._out = None
         self._image = torch.zeros((self.n, 9, 8, 8), dtype=self.dtype, device=self.device)
         self.sims_run = 0
 
@@ -100,8 +103,20 @@ class SelfPlayEngine:
         return (g / g.sum(1, keepdim=True)).contiguous()
 
     # ---- one search for every game (main.py:75-87) -------------------------------------------------
+    def _net_out(self):
+        """one reused set of network outputs when the engine offers it (InferenceEngine on the HIP path): every result is
+        consumed by the tree kernel that follows before the next inference is issued on the same stream"""
+        if self._out is None and getattr(self.net, "tower", None) == "hip" and hasattr(self.net, "output_buffers") and \
+                os.environ.get("MZ_NO_OUT_REUSE") != "1":
+            self._out = self.net.output_buffers(self.n)
+        return self._out
+
+    def _recurrent(self):
+        out = self._net_out()
+        return self.net.recurrent(self.mcts.net_in) if out is None else self.net.recurrent(self.mcts.net_in, out=out)
+
     def _sim_step(self):
-        v, p, h = self.net.recurrent(self.mcts.net_in)
+        v, p, h = self._recurrent()
         h = h.reshape(self.n, 8, 8, 8)
         L.call("mz_mcts_backup_select", *self.mcts._args(), L.dptr(v), L.dptr(p), L.dptr(h), L.dptr(self.mcts.net_in),
                self.n, L.current_stream())
@@ -131,7 +146,8 @@ class SelfPlayEngine:
 
     def search(self, image, noise="auto"):
         """root set-up + S simulations for all games. Returns (visits (n,65) i32, root_value (n,) f32)."""
-        v0, p0, h0 = self.net.initial(image)
+        out = self._net_out()
+        v0, p0, h0 = self.net.initial(image) if out is None else self.net.initial(image, out=out)
         legal, to_play = self.env.legal, self.env.to_play
         if isinstance(noise, str):
             noise = self.dirichlet_noise(legal)
@@ -145,14 +161,14 @@ class SelfPlayEngine:
                 for _ in range(full):
                     self._graph.replay()
                 for _ in range(rest):   # only when graph_steps was set below S - 1
-                    v, p, h = self.net.recurrent(self.mcts.net_in)
+                    v, p, h = self._recurrent()
                     self.mcts.backup_select(v, p, h.reshape(self.n, 8, 8, 8))
                 self.mcts.sims_done += full * self._graph_steps
             else:
                 for _ in range(S - 1):
-                    v, p, h = self.net.recurrent(self.mcts.net_in)
+                    v, p, h = self._recurrent()
                     self.mcts.backup_select(v, p, h.reshape(self.n, 8, 8, 8))
-            v, p, h = self.net.recurrent(self.mcts.net_in)
+            v, p, h = self._recurrent()
             self.mcts.expand_backup(v, p, h.reshape(self.n, 8, 8, 8).contiguous())
             self.sims_run += S * self.n
         return self.mcts.root_stats()
