@@ -66,7 +66,7 @@ def _ref_tower(x, first, blocks, last):
     return q(torch.relu(conv(y, last)))
 
 
-@pytest.mark.parametrize("n", [4096, 6001, 203, 1])
+@pytest.mark.parametrize("n", [4096, 6001, 9001, 203, 1])
 def test_hip_tower_vs_torch_fp32_reference(n):
     """mz_tower_forward (both towers) through the C ABI against the fp32 reference; ragged n covers partial tiles, and
     6001 boards = 1501 tiles gives the persistent workgroups 5 or 6 tiles each (heads batches of 4 + 1 and 4 + 2)"""
