@@ -15,7 +15,8 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 device = torch.device("cuda", 0)
 torch.manual_seed(1261)
 net = InferenceEngine(Network(), n, torch.bfloat16)
-eng = SelfPlayEngine(n, net, num_simulations=S, device=device, use_graph=True, seed=1261)
+POOL_S = int(os.environ.get("MZ_TREE_BENCH_POOL_SIMS", S))   # size the pool for more simulations than are run (page-spread experiment)
+eng = SelfPlayEngine(n, net, num_simulations=POOL_S, device=device, use_graph=True, seed=1261)
 roots, hw, hb, idx = B.make_roots(n, 1261, 0, device)
 eng.env = roots
 image = make_image(hw, hb, idx, n, torch.bfloat16)
@@ -47,6 +48,9 @@ for rep in range(8):
         launches += S - 1
 assert os.environ.get("MZ_TREE_BENCH_NOCHECK") or torch.equal(eng.mcts.root_stats()[0], vis)
 # the whole search as the bench times it (graph replay: tower + tree per simulation)
+if POOL_S != S:
+    print("k_backup_select %.2f us per launch (%d trees, %d simulations in a pool sized for %d, mean depth %.2f)" % (tot / launches * 1e3, n, S, POOL_S, depth / (S - 1)))
+    sys.exit(0)
 for _ in range(3):
     eng.search(image)
 torch.cuda.synchronize()
