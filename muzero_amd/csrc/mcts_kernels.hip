@@ -151,6 +151,17 @@ __device__ __forceinline__ Mx ucb_score(const ChildRec &r, const PbcRec &pb, con
 // Python-float kind (D) are ordered among themselves in double; a tensor-kind item (F) compares
 // equal to every item with the same key.  See DESIGN.md for the proof of equivalence.
 __device__ __forceinline__ int select_argmax(bool valid, Mx s, bool valid64, Mx s64, int lane, bool tie_lowest) {
+    {   // max() never replaces its running result across a comparison with NaN (every such comparison is False): NaN items are
+        // skipped -- the fmax reductions below do that -- but a NaN FIRST item stays the result.  (Scores are NaN when the
+        // policy mass of the expanded actions is zero: priors 0/0.)
+        const uint64_t mvalid = __ballot(valid), mnan = __ballot(valid && s.d != s.d);
+        if (mvalid) {
+            const int first = lo_bit(mvalid);
+            if ((mnan >> first) & 1ULL) return first;
+        } else if (valid64 && s64.d != s64.d) {
+            return 64;
+        }
+    }
     const float key = valid ? mx_f(s) : -INFINITY;
     const float key64 = valid64 ? mx_f(s64) : -INFINITY;
     const float K = fmaxf(wave_max_f32(key), key64);
