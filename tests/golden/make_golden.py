@@ -711,10 +711,140 @@ def gen_bulk(n_games=131072):
     assert stats["mismatched_digests"] == stats["mismatched_actions"] == stats["mismatched_done"] == 0
 
 
+# ------------------------------------------------------------------------------------------------
+# bulk verdict for the SEARCH (main.py:99-196): >= 10k reference searches against the oracle, verdict only
+# ------------------------------------------------------------------------------------------------
+BULK_S = (50, 60, 50, 100, 60, 50, 60, 200, 50, 60, 100, 60)           # S by job % 12 (mean 75)
+BULK_MODES = ("hash", "sat", "const", "uniform", "hash", "hash")        # by (job // 12) % 6
+BULK_BOUNDS = ((-1, 1), None, (-0.25, 0.3), (-1, 1), (-0.1, 0.7), (-1, 1), None)   # by (job // 5) % 7; ints as config.py has them
+BULK_DISCOUNT = (1.0, 0.9, 1.0, 0.997, 1.0)                             # by (job // 3) % 5
+
+
+def _bulk_mcts_plan(job):
+    S = BULK_S[job % 12]
+    mode = BULK_MODES[(job // 12) % 6]
+    bounds = BULK_BOUNDS[(job // 5) % 7]
+    disc = BULK_DISCOUNT[(job // 3) % 5]
+    noise = (job % 4) != 3
+    n_moves = (job * 7) % 60                 # 7 is coprime to 60: every depth 0..59 equally often
+    want_pass_root = (job % 16) == 9         # a sixteenth of the jobs look for a pass-only root in their game
+    return S, mode, bounds, disc, noise, n_moves, want_pass_root
+
+
+def _bulk_mcts_chunk(args):
+    """a chunk of jobs: reference search (instrumented main.run_mcts) and oracle search on the same root, compared here"""
+    job0, n = args
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import mz_oracle as O
+    st = dict(searches=0, simulations=0, mism_visits=0, mism_w_bits=0, mism_prior_bits=0, mism_root_value_bits=0, mism_root_n=0,
+              mism_depth=0, mism_leaf_action=0, mism_paths=0, paths_checked_searches=0, max_depth=0, pass_only_roots=0,
+              by_S={}, by_mode={}, by_bounds={}, by_discount={}, by_noise={}, by_moves_decile={})
+    game0 = 1 << 21
+    for job in range(job0, job0 + n):
+        S, mode, bounds, disc, use_noise, n_moves, want_pass = _bulk_mcts_plan(job)
+        g = game0 + job
+        if want_pass:   # first position of this game where the mover has no move (reversi.py:124-125), if any before step 57
+            game = M.Game()
+            for step in range(57):
+                s = env_state(game.environment)
+                if s[6]:
+                    break
+                game.apply(M.Action(R.playout_action(SEED, g, step, s[5]), game.to_play()))
+        else:
+            game = reach_position(g, n_moves)
+        net = HashNetwork(mode)
+        res = run_reference_search(game, net, S, 70000 + job, use_noise, bounds, disc)
+        t = O.Tree(S, discount=disc, known_bounds=bounds)
+        noise = res["noise"] if use_noise else None
+        h0 = R.hashnet_image_hash(res["image"])
+        _, depth, leaf_a = t.search_hashnet(res["to_play"], res["legal"], res["pass_flag"], noise, h0, R.MODES[mode], S)
+        visits, wsum, prior, rn, rv = t.root_stats()
+        ref_depth = np.array([len(p) for p in res["paths"]], np.int32)
+        ref_leaf = np.array([p[-1] for p in res["paths"]], np.uint8)
+        st["searches"] += 1
+        st["simulations"] += S
+        st["mism_visits"] += int((visits != res["visits"]).any())
+        st["mism_w_bits"] += int((wsum.view(np.uint32) != res["wsum"].view(np.uint32)).any())
+        st["mism_prior_bits"] += int((prior.view(np.uint64) != res["prior"].view(np.uint64)).any())
+        st["mism_root_value_bits"] += int(np.float32(rv).view(np.uint32) != res["root_value"].view(np.uint32))
+        st["mism_root_n"] += int(rn != res["root_n"])
+        st["mism_depth"] += int((depth != ref_depth).any())
+        st["mism_leaf_action"] += int((leaf_a != ref_leaf).any())
+        if job % 8 == 0:   # every eighth search also replays the oracle step by step and compares WHOLE paths per simulation
+            t2 = O.Tree(S, discount=disc, known_bounds=bounds)
+            t2.root_init(res["to_play"], res["legal"], res["pass_flag"], res["root_policy"], noise)
+            node_h = {0: h0}
+            bad = 0
+            for s_ in range(S):
+                d, pid, a, plane, path = t2.select()
+                want = res["paths"][s_]
+                bad |= int(len(path) != len(want) or (path != np.array(want)).any())
+                hh = R.hashnet_step(node_h[pid], R.action_code(a, plane))
+                node_h[s_ + 1] = hh
+                v, p = R.hashnet_outputs(hh, mode)
+                t2.expand_backup(v, p)
+            st["mism_paths"] += bad
+            st["paths_checked_searches"] += 1
+        st["max_depth"] = max(st["max_depth"], int(ref_depth.max()))
+        st["pass_only_roots"] += int(res["pass_flag"])
+        for key, val in (("by_S", S), ("by_mode", mode), ("by_bounds", str(bounds)), ("by_discount", disc),
+                         ("by_noise", int(use_noise)), ("by_moves_decile", int(res["steps"]) // 10)):
+            st[key][str(val)] = st[key].get(str(val), 0) + 1
+    M.config.num_simulations, M.config.known_bounds, M.config.discount = 60, (-1, 1), 1.0
+    return st
+
+
+def gen_bulk_mcts(n_searches=10240):
+    """Every search is run by the imported reference (main.expand_node / add_exploration_noise / run_mcts on HashNet, the
+    harness of run_reference_search) and by the oracle (mzo_search_hashnet) on the same root, noise and knobs; compared
+    in-process: visit counts, child value_sum bits, prior bits (float64), root value bits, root visit count, and per
+    simulation the path depth and the leaf action (whole paths on every eighth search).  Only the verdict is written:
+    tests/golden/bulk_mcts_verdict.json."""
+    import json
+    import multiprocessing as mp
+    import time
+    t0 = time.time()
+    chunk = 16
+    jobs = [(j, min(chunk, n_searches - j)) for j in range(0, n_searches, chunk)]
+    tot = None
+    with mp.Pool(8) as pool:
+        for k, st in enumerate(pool.imap_unordered(_bulk_mcts_chunk, jobs)):
+            if tot is None:
+                tot = st
+            else:
+                for key, v in st.items():
+                    if isinstance(v, dict):
+                        for kk, vv in v.items():
+                            tot[key][kk] = tot[key].get(kk, 0) + vv
+                    elif key == "max_depth":
+                        tot[key] = max(tot[key], v)
+                    else:
+                        tot[key] += v
+            if k % 16 == 0:
+                print("bulk_mcts: %d searches, %.0f s, mismatching searches so far %d" % (
+                    tot["searches"], time.time() - t0, sum(v for kk, v in tot.items() if kk.startswith("mism_"))), flush=True)
+    for key in list(tot):
+        if isinstance(tot[key], dict):
+            tot[key] = dict(sorted(tot[key].items()))
+    tot["mismatches"] = sum(v for kk, v in tot.items() if kk.startswith("mism_"))
+    tot.update(first_game_id=1 << 21, seed=SEED, seconds=round(time.time() - t0, 1), processes=8,
+               reference="/root/reference/main.py expand_node + add_exploration_noise + run_mcts (select_child, ucb_score, "
+                         "backpropagate, MinMaxStats) imported in the build container, HashNet as the network",
+               compared="per search: visits[65], value_sum bits (f32), prior bits (f64), root value bits, root N, per-simulation depth "
+                        "and leaf action (whole paths on every 8th search) vs oracle/mz_oracle.c mzo_search_hashnet")
+    with open(os.path.join(HERE, "bulk_mcts_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["mismatches"] == 0
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "bulk":
         gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
+    if what == "bulk_mcts":
+        gen_bulk_mcts(int(sys.argv[2]) if len(sys.argv) > 2 else 10240)
         sys.exit(0)
     if what in ("env", "all"):
         gen_env()

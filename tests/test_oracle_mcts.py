@@ -153,3 +153,21 @@ def test_whole_games(golden_dir):
         cv = np.stack([O.child_visits(v) for v in visits])
         assert (cv == g["child_visits_%d" % i]).all()
         assert root_values.view(np.uint32).tolist() == g["root_values_%d" % i].view(np.uint32).tolist()
+
+
+def test_bulk_reference_search_verdict_is_committed_and_clean(golden_dir):
+    """>= 10k searches run by the IMPORTED reference (main.expand_node / add_exploration_noise / run_mcts on HashNet;
+    tests/golden/make_golden.py bulk_mcts, build container only) against this oracle's mzo_search_hashnet on the same roots,
+    noise and knobs: visits, value_sum bits, prior bits, root value bits, per-simulation depth and leaf action (whole paths on
+    every eighth search).  Only the verdict travels; a sample of the plan is re-run against the oracle here to show that the
+    recorded knobs are the ones this code still understands."""
+    import json
+    v = json.load(open(os.path.join(golden_dir, "bulk_mcts_verdict.json")))
+    assert v["searches"] >= 10_000 and v["mismatches"] == 0
+    for k in ("mism_visits", "mism_w_bits", "mism_prior_bits", "mism_root_value_bits", "mism_root_n", "mism_depth", "mism_leaf_action",
+              "mism_paths"):
+        assert v[k] == 0, k
+    assert v["paths_checked_searches"] >= 1000 and v["pass_only_roots"] >= 50 and v["max_depth"] >= 6
+    assert set(v["by_S"]) == {"50", "60", "100", "200"} and set(v["by_mode"]) == {"hash", "sat", "const", "uniform"}
+    assert {"None", "(-1, 1)", "(-0.25, 0.3)"} <= set(v["by_bounds"]) and {"0.9", "0.997", "1.0"} <= set(v["by_discount"])
+    assert min(v["by_noise"].values()) >= 2000 and len(v["by_moves_decile"]) == 6
