@@ -159,8 +159,7 @@ def test_bulk_reference_search_verdict_is_committed_and_clean(golden_dir):
     """>= 10k searches run by the IMPORTED reference (main.expand_node / add_exploration_noise / run_mcts on HashNet;
     tests/golden/make_golden.py bulk_mcts, build container only) against this oracle's mzo_search_hashnet on the same roots,
     noise and knobs: visits, value_sum bits, prior bits, root value bits, per-simulation depth and leaf action (whole paths on
-    every eighth search).  Only the verdict travels; a sample of the plan is re-run against the oracle here to show that the
-    recorded knobs are the ones this code still understands."""
+    every eighth search).  Only the verdict travels."""
     import json
     v = json.load(open(os.path.join(golden_dir, "bulk_mcts_verdict.json")))
     assert v["searches"] >= 10_000 and v["mismatches"] == 0
