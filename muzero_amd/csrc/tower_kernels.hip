@@ -130,28 +130,47 @@ __device__ __forceinline__ bf16x8 lds_frag(const char *p) { return *reinterpret_
 // one weight stage (8 KB) global -> LDS by LDS-DMA: each of the 8 waves moves 1 KB with ONE instruction
 // (lane-linear: LDS address = wave-uniform base + 16 * lane), no VGPRs, no ds_write.  The packed image is
 // already in LDS order, so the source is linear too.
+// Written as inline asm in its SGPR-base + 32-bit lane offset form (m0 = the wave's LDS address, s_nop for the m0 hazard).
+// With the builtin anywhere in a loop, hipcc (ROCm 7.2) treats the LDS-DMA as a FLAT access that may return out of order and
+// turns every counted lgkmcnt(N) it would place in front of an MFMA into lgkmcnt(0): the K loop's streamed fragment reads
+// then expose their whole LDS latency (tools/mfma_rate.hip: 83.4 % of the matrix pipe with the builtin, 91.5 % with this form).
+// The compiler does not see this load's vmcnt: every wait for it is written by hand (s_waitcnt vmcnt(N) in the barriers).
+__device__ __forceinline__ void dma_piece(uint32_t lds_addr_wave, const void *__restrict__ src_uniform, uint32_t lane_off) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr_wave), "v"(lane_off), "s"(src_uniform) : "memory");
+}
+// LDS byte address (wave-uniform, in an SGPR) of wave tid >> 6's 1 KB piece of the region at byte offset off
+__device__ __forceinline__ uint32_t wave_lds_addr(char *lds, int off, int tid) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds + off) + (tid >> 6) * 1024);
+}
 __device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restrict__ stage, int tid) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(stage + tid),
-                                     (__attribute__((address_space(3))) void *)(ring_buf + (tid >> 6) * 1024), 16, 0, 0);
+    dma_piece(wave_lds_addr(ring_buf, 0, tid), stage, (uint32_t)tid * 16u);
 }
 
 // ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
-// K loop: 36 stages of [128 co][32 ci] weights (8 KB = one K = 32 step = 16 MFMAs per wave) through a
-// ring of FOUR LDS buffers filled by LDS-DMA, software-pipelined one whole stage deep:
-//   iteration i, after barrier B_i:  run the 16 MFMAs of stage i on the fragment set read during
-//   iteration i-1, read the 8 fragments of stage i+1 into the other set (between the MFMAs), and issue
-//   the DMA of stage i+3 into the buffer stage i-1 has left.
-// B_i (s_waitcnt vmcnt(1) + s_barrier) orders "all waves finished reading stage i-1" (its buffer is
-// free) and "every wave's DMA piece of stage i+1 has landed", so stage i+1 is readable anywhere in
-// iteration i.  Nothing an MFMA consumes was requested less than a stage ago, and the barrier's
-// lgkmcnt(0) finds its reads done.
-// The weight stream is one contiguous array over all six layers (+ 4 stages of padding): it simply
-// keeps running across layer boundaries, so only the first layer pays a prologue (mid_prologue).
-// Halo: a lane whose shifted position leaves the board reads its fragment from a 256-byte block of
-// zeros (OFF_Z) instead -- the select is on the ADDRESS, once per tap, so nothing waits on the data.
+// K loop: 36 stages of [128 co][32 ci] weights (8 KB = one K = 32 step = 16 MFMAs per wave) through a ring of FOUR LDS buffers
+// filled by LDS-DMA.  A stage is four j-steps (j = position tile): 4 MFMAs (the stage's 4 weight fragments x activation fragment
+// j), one activation fragment read and one weight fragment read:
+//   iteration st, behind barrier B_st:
+//     j = 0..3:  MFMA(0,j) MFMA(1,j) | refill the activation slot j-step j - 1 has left: B_st[3] at j = 0, then B_st+1[0..2] |
+//                MFMA(2,j) MFMA(3,j) | weight fragment A_st+1[j] into the other weight set
+//     behind j = 0: the DMA of stage st + 3 into the buffer stage st - 1 has left
+// so activation fragments stream three j-steps ahead of their MFMAs through 4 slots, weight fragments one stage ahead through 2
+// sets, and NO wait of the loop is an lgkmcnt(0): hipcc places a counted lgkmcnt(N) in front of each j-step (it can, because
+// the DMA is inline asm: dma_piece), and the barrier waits for DMA pieces only.
+// B_st (s_waitcnt vmcnt(1) + s_barrier) orders "every wave has issued stage st - 1's MFMAs, so it holds that stage's weight
+// fragments in registers and that buffer is free" and "every wave's piece of stage st + 1 has landed" (all but the youngest
+// DMA, the one of iteration st - 1), so A_st+1 is readable anywhere in iteration st.  No barrier needs the activation reads
+// to be back: the image is not written during the K loop, and a fragment's consumer waits for it by data dependence.
+// The weight stream is one contiguous array over all six layers (+ 4 stages of padding): it simply keeps running across layer
+// boundaries, so only the first layer pays a prologue (mid_prologue).
+// Halo: a lane whose shifted position leaves the board reads its fragment past the end of the LDS allocation (zeros, OFF_Z)
+// -- the select is on the ADDRESS, once per tap.  Position tile j of the wave's board covers board rows 2j, 2j + 1, so the
+// fragment address is (row base of the tap) + 4096 j + (chunk offset of the stage); only tile 0 can leave the board at the top
+// and tile 3 at the bottom: three base registers per tap (main / top / bottom), one add each per stage, the tile's 4096 j as the
+// instruction's immediate offset.
 
 // the first three weight stages of the first mid layer: issued at kernel start (the ring is idle during the
-// first layer), complete by the __syncthreads() that ends the first layer (it drains vmcnt)
+// first layer), complete by the vmcnt(0) + barrier that ends the first layer
 __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict__ wp, int tid) {
     dma_stage(lds + OFF_W, wp, tid);
     dma_stage(lds + OFF_W + WSTAGE_BYTES, wp + 512, tid);
@@ -170,7 +189,6 @@ __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict_
 //   A (weights):     lane l -> row co = 16 i + (l & 15), k = 8 (l >> 4) + 0..7  = the l >> 4 -th 16-byte chunk of the 64-byte row
 //   B (activations): lane l -> col pos = 16 j + (l & 15), same k                 = chunk 4 kq + (l >> 4) of the 256-byte row
 //   D:               lane l -> col pos, rows co = 16 i + 4 (l >> 4) + 0..3       = 8 bytes of the [pos][ch] image
-struct Frags16 { bf16x8 a[4], b[4]; };
 typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
 template <bool RES>
@@ -186,101 +204,106 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
 
-    char *wring = lds + OFF_W;
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
     int waddr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = cobase + 16 * i + c16;
-        waddr[i] = co * 64 + ((kc ^ ((0x78 >> (((co >> 2) & 3) * 2)) & 3)) << 4);
+        waddr[i] = OFF_W + co * 64 + ((kc ^ ((0x78 >> (((co >> 2) & 3) * 2)) & 3)) << 4);
     }
-    // activations per tap: row base (or the out-of-range zero block) and (kc ^ key) << 4; tile j = board rows 2j, 2j + 1
-    int arow[4], ak4[4];
+    const uint32_t ring_m0 = wave_lds_addr(lds, OFF_W, tid);   // this wave's 1 KB piece of ring buffer 0
+    const uint32_t lane_off = (uint32_t)tid * 16u;
+    // activations, per tap: the three row bases (or the out-of-range zero block) and the chunk key; per stage: + chunk offset
+    int tbm, tbt, tbb, ak, am, at, ab;
     const int x = p16 & 7, y0 = p16 >> 3;
     auto set_tap = [&](int ky, int kx) {   // tap = 3 ky + kx
         const int dq = (ky - 1) * 8 + (kx - 1);
         const bool okx = (unsigned)(x + kx - 1) < 8u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q2 = (posbase + 16 * j + p16 + dq) & 255;
-            const bool ok = okx && (unsigned)(2 * j + y0 + ky - 1) < 8u;
-            arow[j] = ok ? src_off + q2 * 256 : OFF_Z;
-            ak4[j] = (kc ^ act_key(q2)) << 4;
-        }
+        const int base = src_off + (posbase + p16 + dq) * 256;   // tile 0's shifted row; tile j: + 4096 j
+        ak = (kc ^ act_key((p16 + dq) & 15)) << 4;               // the key's bits (row parity, column) do not depend on the tile
+        tbm = okx ? base : OFF_Z;
+        tbt = okx && (y0 + ky - 1) >= 0 ? base : OFF_Z;          // tile 0 = board rows 0, 1
+        tbb = okx && (6 + y0 + ky - 1) < 8 ? base : OFF_Z;       // tile 3 = board rows 6, 7
     };
-    auto load_stage = [&](int st, Frags16 &f) {
-        const char *wb = wring + (st & 3) * WSTAGE_BYTES;
-        const int kq = st & 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f.a[i] = lds_frag(wb + waddr[i]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f.b[j] = lds_frag(lds + arow[j] + ((kq * 64) ^ ak4[j]));
+    auto set_kq = [&](int kq) {
+        const int off = (kq * 64) ^ ak;
+        am = tbm + off;
+        at = tbt + off;
+        ab = tbb + off;
     };
+    auto bfrag = [&](int j) { return lds_frag(lds + (j == 0 ? at : (j == 3 ? ab : am)) + j * 4096); };
 
-    Frags16 fr[2];
+    bf16x8 a[2][4], b[4];
     set_tap(0, 0);
-    load_stage(0, fr[0]);
+    set_kq(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = bfrag(j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = lds_frag(lds + waddr[i]);
 
     // 3 trips x 12 stages (3 taps): ring index, channel quarter and the register-set parity are compile-time constants
-    // and the body is branch-free.  The last trip prefetches "tap 9" (every lane on the zero block) and stages 36..38
-    // (the next layer's first stages, or the padding): harmless, and no tail conditions.
+    // and the body is branch-free.  The last trip prefetches "tap 9" fragments (any address is a legal LDS read; they are
+    // never used) and stages 36..38 (the next layer's first stages, or the padding): harmless, and no tail conditions.
 #pragma unroll 1
     for (int T = 0; T < 3; ++T) {
         const uint4 *wt = wp + (T * 12 + 3) * 512;
 #pragma unroll
         for (int ss = 0; ss < 12; ++ss) {
             // all but the youngest DMA (stage st + 2, issued one iteration ago) have landed: stage st + 1 is complete
-#ifndef MZ_EXP_NOBARRIER   // diagnostic builds only (-DMZ_EXP_NOBARRIER / -DMZ_EXP_NOWEIGHTS: wrong results, used with tools/tower_stamps.py to price the barrier and the DMA)
-            asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            // hand-ordered issue, fenced with sched_barrier(0) (hipcc otherwise sinks the prefetch reads to their use and
-            // exposes every stage to the LDS latency): MFMAs first, so the matrix pipe restarts right behind the barrier;
-            // two fragment reads of stage st + 1 behind every second MFMA; the last MFMAs cover those reads' latency
-            // before the next barrier's lgkmcnt(0); the weight DMA (60-180 cycles of issue) goes last, into the wave's
-            // own MFMA drain.
-            const Frags16 &c = fr[ss & 1];
-            Frags16 &nx = fr[(ss + 1) & 1];
-            const char *wb = wring + ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
-            const int kq = (ss + 1) & 3;
-#define MZ_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c.a[i], c.b[j], acc[i][j], 0, 0, 0)
+            asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
+            const bf16x8(&ca)[4] = a[ss & 1];
+            bf16x8(&na)[4] = a[(ss + 1) & 1];
+            const int nbuf = ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
+#define MZ_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], b[j], acc[i][j], 0, 0, 0)
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
+            // j = 0
             MZ_MFMA(0, 0);
-            MZ_MFMA(0, 1);
-            MZ_FENCE();
-            if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
-            nx.a[0] = lds_frag(wb + waddr[0]);
-            nx.a[1] = lds_frag(wb + waddr[1]);
-            MZ_FENCE();
-            MZ_MFMA(0, 2);
-            MZ_MFMA(0, 3);
-            MZ_FENCE();
-            nx.b[0] = lds_frag(lds + arow[0] + ((kq * 64) ^ ak4[0]));
-            nx.b[1] = lds_frag(lds + arow[1] + ((kq * 64) ^ ak4[1]));
-            MZ_FENCE();
             MZ_MFMA(1, 0);
-            MZ_MFMA(1, 1);
             MZ_FENCE();
-            nx.a[2] = lds_frag(wb + waddr[2]);
-            nx.a[3] = lds_frag(wb + waddr[3]);
-            MZ_FENCE();
-            MZ_MFMA(1, 2);
-            MZ_MFMA(1, 3);
-            MZ_FENCE();
-            nx.b[2] = lds_frag(lds + arow[2] + ((kq * 64) ^ ak4[2]));
-            nx.b[3] = lds_frag(lds + arow[3] + ((kq * 64) ^ ak4[3]));
+            b[3] = bfrag(3);   // this stage's last tile (its slot was left by the previous stage's j = 3)
             MZ_FENCE();
             MZ_MFMA(2, 0);
-            MZ_MFMA(2, 1);
-            MZ_MFMA(2, 2);
-            MZ_MFMA(2, 3);
             MZ_MFMA(3, 0);
+            MZ_FENCE();
+            na[0] = lds_frag(lds + nbuf + waddr[0]);
+            MZ_FENCE();
+            dma_piece(ring_m0 + ((ss + 3) & 3) * WSTAGE_BYTES, wt + ss * 512, lane_off);   // stage st + 3 -> the buffer stage st - 1 left
+            // the addresses of stage st + 1 (next channel quarter, or the next tap's first)
+            if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
+            set_kq((ss + 1) & 3);
+            MZ_FENCE();
+            // j = 1
+            MZ_MFMA(0, 1);
+            MZ_MFMA(1, 1);
+            MZ_FENCE();
+            b[0] = bfrag(0);
+            MZ_FENCE();
+            MZ_MFMA(2, 1);
             MZ_MFMA(3, 1);
+            MZ_FENCE();
+            na[1] = lds_frag(lds + nbuf + waddr[1]);
+            MZ_FENCE();
+            // j = 2
+            MZ_MFMA(0, 2);
+            MZ_MFMA(1, 2);
+            MZ_FENCE();
+            b[1] = bfrag(1);
+            MZ_FENCE();
+            MZ_MFMA(2, 2);
             MZ_MFMA(3, 2);
+            MZ_FENCE();
+            na[2] = lds_frag(lds + nbuf + waddr[2]);
+            MZ_FENCE();
+            // j = 3
+            MZ_MFMA(0, 3);
+            MZ_MFMA(1, 3);
+            MZ_FENCE();
+            b[2] = bfrag(2);
+            MZ_FENCE();
+            MZ_MFMA(2, 3);
             MZ_MFMA(3, 3);
             MZ_FENCE();
-#ifndef MZ_EXP_NOWEIGHTS
-            dma_stage(wring + ((ss + 3) & 3) * WSTAGE_BYTES, wt + ss * 512, tid);   // stage st + 3 -> the buffer stage st - 1 left
-#endif
+            na[3] = lds_frag(lds + nbuf + waddr[3]);
             MZ_FENCE();
 #undef MZ_MFMA
 #undef MZ_FENCE
@@ -288,16 +311,19 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     }
 
     MZ_STAMP(tw, stamp_id);
+    // every wave is through its MFMAs (so through its reads of the source image and of the ring) before anything below
+    // writes the destination image: with RES the destination is read too, and dst may be what another wave's "tap 9"
+    // prefetch is still reading -- harmless for values, but the epilogue's own reads must see the image before any write to
+    // it only where they alias their own cells (they do: each lane reads and writes its own 8 bytes).  The stage-35 MFMAs
+    // of EVERY wave must be issued before T is overwritten by the last layer's weights (tail_dma): that needs a barrier.
     // behind the last mid layer: the LAST conv layer's weights (20 KB, already in LDS order) go into the T image by
-    // LDS-DMA now, under this epilogue.  T is free: after the K loop's last barrier no wave reads it any more (stage 35's
-    // fragments were read during stage 34, and the "tap 9" prefetch reads the zero block).
+    // LDS-DMA now, under this epilogue.  T is free once every wave has read its last fragments of it.
     if (tail_dma) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int piece = w + 8 * k;   // 1 KB pieces, wave-uniform
-            if (piece < LAST_W_BYTES / 1024)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tail_dma + piece * 64 + lane),
-                                                 (__attribute__((address_space(3))) void *)(lds + OFF_T + piece * 1024), 16, 0, 0);
+            if (piece < LAST_W_BYTES / 1024) dma_piece(wave_lds_addr(lds, OFF_T + 8192 * k, tid), tail_dma + 8 * k * 64, lane_off);
         }
     }
     // the next layer's bias: two thousand cycles of epilogue ahead of its first use
@@ -332,7 +358,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
             *reinterpret_cast<uint2 *>(p) = o;
         }
     }
-    // raw barrier (LDS only): the two weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 and are
+    // raw barrier (LDS only): the weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 and are
     // retired by its first counted waits; __syncthreads() would stall every layer boundary on them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -410,6 +436,8 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
                 if (!(MZ_DIAG & 8) || o.x == 0x12345678u) *reinterpret_cast<uint2 *>(p) = o;
             }
         }
+    // the weight prologue's DMA pieces (mid_prologue: inline asm, invisible to the compiler's own waits) have landed too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
