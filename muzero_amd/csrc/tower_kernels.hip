@@ -6,25 +6,28 @@
 // the same launch, the prediction heads (network.py:79-111), so one kernel returns the whole
 // (value, policy, hidden) tuple of initial_inference / recurrent_inference (network.py:146-163).
 //
-// Why one kernel.  An 8x8 board with 128 channels is 16 KB in bf16, so FOUR boards (256 positions,
-// the GEMM N dimension) and both activation tensors a residual block needs fit in the 160 KB LDS of
-// one CU.  A workgroup therefore carries its four boards through all eight layers without ever
-// writing an activation to HBM: per tile it reads 5 KB of input planes, writes 4 KB of hidden
-// state, and streams the layer weights (295 KB per 128->128 layer, L2-resident: every workgroup
-// reads the same 1.9 MB) through a ring of four 8 KB LDS buffers.  HBM traffic drops from
-// ~200 MB per layer to ~27 MB per launch; what is left is MFMA work.
+// Why one kernel.  An 8x8 board with 128 channels is 16 KB in bf16, so EIGHT boards (512 positions, the GEMM N dimension)
+// fit in 128 KB of the CU's 160 KB LDS as ONE activation image that every layer updates in place.  A workgroup therefore
+// carries its eight boards through all eight layers without ever writing an activation to HBM: per tile it reads 10 KB of
+// input planes, writes 8 KB of hidden state, and streams the layer weights (295 KB per 128->128 layer, L2-resident: every
+// workgroup reads the same 1.9 MB) through a ring of four 8 KB LDS buffers.  What is left is MFMA work.
 //
-// Mapping (one workgroup = 512 threads = 8 waves, 2 per SIMD; static LDS = 163,840 B = X image 64 KB |
-// T image 64 KB | weight ring 4 x 8 KB):
+// Mapping (one workgroup = 512 threads = 8 waves, 2 per SIMD; static LDS = 163,840 B = activation image 128 KB | weight
+// ring 4 x 8 KB):
 //   GEMM per layer: D[co][pos] = sum_{tap,ci} W[tap][co][ci] * X[pos + shift(tap)][ci]
 //   v_mfma_f32_16x16x32_bf16 (first layer: 32x32x16) with A = weights (rows = co), B = activations
 //   (cols = pos), so a lane ends up holding ONE position and 4-element runs of consecutive channels: the
-//   epilogue (residual, bf16 rounding, ReLU) writes 8-byte pieces straight back into the [pos][ch] LDS
+//   epilogue (bf16 rounding, ReLU) writes 8-byte pieces straight back into the [pos][ch] LDS
 //   image the next layer reads -- no transpose, no shuffle.  The accumulators start at the bias.
-//   wave w: co half (w & 1) x board (w >> 1)  ->  a 4 x 4 grid of 16 x 16 accumulators per wave.
-//   K loop: 9 taps x 4 channel quarters = 36 stages of [128 co][32 ci], filled by LDS-DMA three stages
-//   ahead; one counted raw barrier per stage, and fragment reads run one whole stage ahead ACROSS the
-//   barrier (layer_mid), so the MFMA stream never drains at a stage boundary.
+//   wave w: co half (w & 1) x board pair (w >> 1)  ->  a 4 x 8 grid of 16 x 16 accumulators per wave (128 registers).
+//   In place: a layer's whole output lives in the workgroup's accumulators when its K loop ends, so after one barrier
+//   the epilogue overwrites the image it has just read.  The residual x + conv(relu(conv(x))) needs no second image either:
+//   the epilogue of a block's first convolution reads each lane's own cells of x before it overwrites them with t and
+//   leaves x + bias in the accumulators the second convolution then adds into.
+//   K loop: 9 taps x 4 channel quarters = 36 stages of [128 co][32 ci] (one 8 KB weight stage feeds 32 MFMAs per wave,
+//   twice what a 4-board tile gives it, and a stage's 12 fragment reads serve those 32 MFMAs: less LDS and L2 traffic per
+//   MFMA is what lets the chip hold its clock -- the kernel is power-limited), filled by LDS-DMA three stages ahead;
+//   one barrier per stage that waits for DMA pieces only.
 //   The 3x3 halo needs no padding ring in the activation image: a lane whose shifted position leaves
 //   the board reads its fragment past the end of the LDS allocation, which returns zeros (OFF_Z).
 // LDS images are XOR-swizzled in 16-byte chunks so every ds_read_b128 lane group hits 16 distinct
@@ -34,29 +37,27 @@
 // is a linear copy.
 #include "common.h"
 
-#ifndef MZ_DIAG
-#define MZ_DIAG 0   // diagnostic builds only (tools/build_variant.sh ... -DMZ_DIAG=mask): pieces of the non-K-loop phases are skipped to price them
-#endif
-
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int TILE_BOARDS = 4;
-constexpr int TILE_POS = 256;
-constexpr int ACT_BYTES = TILE_POS * 128 * 2;  // 65,536: one [256 pos][128 ch] bf16 image
+constexpr int TILE_BOARDS = 8;
+constexpr int TILE_POS = 512;
+constexpr int ACT_BYTES = TILE_POS * 128 * 2;  // 131,072: the [512 pos][128 ch] bf16 image, updated in place by every layer
 constexpr int WSTAGE_BYTES = 128 * 32 * 2;     // 8,192: one [128 co][32 ci] weight stage
-constexpr int OFF_X = 0, OFF_T = ACT_BYTES, OFF_W = 2 * ACT_BYTES;
-constexpr int LDS_BYTES = 2 * ACT_BYTES + 4 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
+constexpr int OFF_X = 0, OFF_W = ACT_BYTES;
+constexpr int LDS_BYTES = ACT_BYTES + 4 * WSTAGE_BYTES;  // 163,840 = all of a CU's LDS
 constexpr int OFF_Z = LDS_BYTES;  // the halo's zero fragment: a DS read at or beyond the workgroup's LDS allocation returns 0
                                   // (hardware bounds check; the allocation is the whole 160 KB, so nothing lies behind it)
 constexpr int N_STAGES = 36;                   // 9 taps x 4 quarters of the input channels
 constexpr int FIRST_W_BYTES = 9 * 128 * 16 * 2;   // 36,864
+constexpr int OFF_FIN = 0, OFF_FW = TILE_POS * 32;   // first layer scratch inside the (not yet written) image: [512 pos][16 ch] input | tap weight slabs
 constexpr int LAST_ROWS = 80;                       // 9 taps x 8 planes = 72 weight rows, padded to five 16-row MFMA tiles
-constexpr int LAST_W_BYTES = 4 * LAST_ROWS * 32 * 2;  // 20,480: [4 channel quarters][80 rows][32 ci]
-constexpr int OFF_P = OFF_T + LAST_W_BYTES;         // the last layer's per-tap partial sums: 72 KB spanning the rest of T and the weight ring
+constexpr int LAST_W_BYTES = 4 * LAST_ROWS * 32 * 2;  // 20,480: [4 channel quarters][80 rows][32 ci], sent into ring buffers 0..2 by the last K loop
+constexpr int P_WAVE_BYTES = 9 * 2 * 64 * 16;       // 18,432: one board's per-tap partial sums of the last layer, [tap][plane half][cell][4 planes] f32
+static_assert(OFF_FW + FIRST_W_BYTES <= ACT_BYTES && 8 * P_WAVE_BYTES <= LDS_BYTES && LAST_W_BYTES <= 3 * WSTAGE_BYTES, "LDS plan");
 
 struct Tower {
     const uint4 *w_first;  // [9][128 co][16 ci] bf16
@@ -146,13 +147,13 @@ __device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restric
     dma_piece(wave_lds_addr(ring_buf, 0, tid), stage, (uint32_t)tid * 16u);
 }
 
-// ---- 128 -> 128 layer: src image -> dst image (dst may be the residual source, updated in place) ----
-// K loop: 36 stages of [128 co][32 ci] weights (8 KB = one K = 32 step = 16 MFMAs per wave) through a ring of FOUR LDS buffers
-// filled by LDS-DMA.  A stage is four j-steps (j = position tile): 4 MFMAs (the stage's 4 weight fragments x activation fragment
-// j), one activation fragment read and one weight fragment read:
+// ---- 128 -> 128 layer, in place in the activation image ----
+// K loop: 36 stages of [128 co][32 ci] weights (8 KB = one K = 32 step = 32 MFMAs per wave) through a ring of FOUR LDS buffers
+// filled by LDS-DMA.  A stage is eight j-steps (j = position tile of the wave's two boards): 4 MFMAs (the stage's 4 weight
+// fragments x activation fragment j), one activation fragment read and, in the first four, one weight fragment read:
 //   iteration st, behind barrier B_st:
-//     j = 0..3:  MFMA(0,j) MFMA(1,j) | refill the activation slot j-step j - 1 has left: B_st[3] at j = 0, then B_st+1[0..2] |
-//                MFMA(2,j) MFMA(3,j) | weight fragment A_st+1[j] into the other weight set
+//     j = 0..7:  MFMA(0,j) MFMA(1,j) | refill the activation slot j-step j - 1 has left with fragment j + 3 (B_st[3..7] at
+//                j = 0..4, then B_st+1[0..2]) | MFMA(2,j) MFMA(3,j) | j < 4: weight fragment A_st+1[j] into the other weight set
 //     behind j = 0: the DMA of stage st + 3 into the buffer stage st - 1 has left
 // so activation fragments stream three j-steps ahead of their MFMAs through 4 slots, weight fragments one stage ahead through 2
 // sets, and NO wait of the loop is an lgkmcnt(0): hipcc places a counted lgkmcnt(N) in front of each j-step (it can, because
@@ -162,12 +163,16 @@ __device__ __forceinline__ void dma_stage(char *ring_buf, const uint4 *__restric
 // DMA, the one of iteration st - 1), so A_st+1 is readable anywhere in iteration st.  No barrier needs the activation reads
 // to be back: the image is not written during the K loop, and a fragment's consumer waits for it by data dependence.
 // The weight stream is one contiguous array over all six layers (+ 4 stages of padding): it simply keeps running across layer
-// boundaries, so only the first layer pays a prologue (mid_prologue).
+// boundaries, so only the first layer pays a prologue (mid_prologue).  The LAST layer's stream ends in the final convolution's
+// weights instead (w_last, 20 KB = 2.5 stages): they arrive in ring buffers 0..2 as "stages 36..38".
 // Halo: a lane whose shifted position leaves the board reads its fragment past the end of the LDS allocation (zeros, OFF_Z)
-// -- the select is on the ADDRESS, once per tap.  Position tile j of the wave's board covers board rows 2j, 2j + 1, so the
-// fragment address is (row base of the tap) + 4096 j + (chunk offset of the stage); only tile 0 can leave the board at the top
-// and tile 3 at the bottom: three base registers per tap (main / top / bottom), one add each per stage, the tile's 4096 j as the
-// instruction's immediate offset.
+// -- the select is on the ADDRESS, once per tap.  Position tile j covers rows 2 (j & 3), 2 (j & 3) + 1 of board j >> 2, so the
+// fragment address is (row base of the tap) + 4096 j + (chunk offset of the stage); only tiles 0 and 4 can leave their board
+// at the top and tiles 3 and 7 at the bottom: three base registers per tap (main / top / bottom), one add each per stage, the
+// tile's 4096 j as the instruction's immediate offset.
+// Epilogue (behind a barrier: every wave is through its reads of the image): each lane rounds its 128 values to bf16, applies
+// ReLU and writes them over the image; MODE 0 (first convolution of a residual block) first reads the cells' old values x and
+// leaves x + bias_next in the accumulators, MODE 1 leaves bias_next: the next K loop starts from them.
 
 // the first three weight stages of the first mid layer: issued at kernel start (the ring is idle during the
 // first layer), complete by the vmcnt(0) + barrier that ends the first layer
@@ -183,26 +188,19 @@ __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict_
     } while (0)
 
 // MFMA shape of the K loop: v_mfma_f32_16x16x32_bf16.  One stage (32 input channels) is exactly one K = 32 step:
-// 4 weight fragments (16 co x 32 ci) x 4 activation fragments (16 positions x 32 ci) -> 16 MFMAs into a 4 x 4 grid of
-// 16 x 16 accumulators.  Same bytes, cycles and registers as eight 32x32x16 MFMAs, but the chip holds a higher clock on
+// 4 weight fragments (16 co x 32 ci) x 8 activation fragments (16 positions x 32 ci) -> 32 MFMAs into a 4 x 8 grid of
+// 16 x 16 accumulators.  Same bytes, cycles and registers as 32x32x16 MFMAs, but the chip holds a higher clock on
 // this shape under sustained load (MI355X_MICROARCH.md, DVFS item 7; measured here: in-kernel clock 1.87 GHz with 32x32x16).
 //   A (weights):     lane l -> row co = 16 i + (l & 15), k = 8 (l >> 4) + 0..7  = the l >> 4 -th 16-byte chunk of the 64-byte row
 //   B (activations): lane l -> col pos = 16 j + (l & 15), same k                 = chunk 4 kq + (l >> 4) of the 256-byte row
 //   D:               lane l -> col pos, rows co = 16 i + 4 (l >> 4) + 0..3       = 8 bytes of the [pos][ch] image
 typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
-template <bool RES>
-__device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, const uint4 *__restrict__ wp, f32x4 (&bv)[4],
-                                          const float *__restrict__ bias_next, const uint4 *__restrict__ tail_dma, int tid, uint32_t vm, const Tower &tw, int stamp_id) {
+template <int MODE>
+__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][8],
+                                          const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
-    const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
-    // the accumulators START at the bias (bv: the lane's 16 values, channels cobase + 16 i + 4 kc + 0..3, requested during
-    // the previous layer's epilogue), so the epilogue has no bias add
-    acc16_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
+    const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
 
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
     int waddr[4];
@@ -219,11 +217,11 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
     auto set_tap = [&](int ky, int kx) {   // tap = 3 ky + kx
         const int dq = (ky - 1) * 8 + (kx - 1);
         const bool okx = (unsigned)(x + kx - 1) < 8u;
-        const int base = src_off + (posbase + p16 + dq) * 256;   // tile 0's shifted row; tile j: + 4096 j
+        const int base = OFF_X + (posbase + p16 + dq) * 256;     // tile 0's shifted row; tile j: + 4096 j
         ak = (kc ^ act_key((p16 + dq) & 15)) << 4;               // the key's bits (row parity, column) do not depend on the tile
         tbm = okx ? base : OFF_Z;
-        tbt = okx && (y0 + ky - 1) >= 0 ? base : OFF_Z;          // tile 0 = board rows 0, 1
-        tbb = okx && (6 + y0 + ky - 1) < 8 ? base : OFF_Z;       // tile 3 = board rows 6, 7
+        tbt = okx && (y0 + ky - 1) >= 0 ? base : OFF_Z;          // tiles 0, 4 = board rows 0, 1
+        tbb = okx && (6 + y0 + ky - 1) < 8 ? base : OFF_Z;       // tiles 3, 7 = board rows 6, 7
     };
     auto set_kq = [&](int kq) {
         const int off = (kq * 64) ^ ak;
@@ -231,7 +229,7 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
         at = tbt + off;
         ab = tbb + off;
     };
-    auto bfrag = [&](int j) { return lds_frag(lds + (j == 0 ? at : (j == 3 ? ab : am)) + j * 4096); };
+    auto bfrag = [&](int j) { return lds_frag(lds + ((j & 3) == 0 ? at : ((j & 3) == 3 ? ab : am)) + j * 4096); };
 
     bf16x8 a[2][4], b[4];
     set_tap(0, 0);
@@ -243,10 +241,11 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
 
     // 3 trips x 12 stages (3 taps): ring index, channel quarter and the register-set parity are compile-time constants
     // and the body is branch-free.  The last trip prefetches "tap 9" fragments (any address is a legal LDS read; they are
-    // never used) and stages 36..38 (the next layer's first stages, or the padding): harmless, and no tail conditions.
+    // never used) and stages 36..38 (the next layer's first stages, or the last convolution's weights).
 #pragma unroll 1
     for (int T = 0; T < 3; ++T) {
         const uint4 *wt = wp + (T * 12 + 3) * 512;
+        const bool tail = w_last != nullptr && T == 2;   // wave-uniform
 #pragma unroll
         for (int ss = 0; ss < 12; ++ss) {
             // all but the youngest DMA (stage st + 2, issued one iteration ago) have landed: stage st + 1 is complete
@@ -254,123 +253,85 @@ __device__ __forceinline__ void layer_mid(char *lds, int src_off, int dst_off, c
             const bf16x8(&ca)[4] = a[ss & 1];
             bf16x8(&na)[4] = a[(ss + 1) & 1];
             const int nbuf = ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
-#define MZ_MFMA(i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], b[j], acc[i][j], 0, 0, 0)
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
-            // j = 0
-            MZ_MFMA(0, 0);
-            MZ_MFMA(1, 0);
-            MZ_FENCE();
-            b[3] = bfrag(3);   // this stage's last tile (its slot was left by the previous stage's j = 3)
-            MZ_FENCE();
-            MZ_MFMA(2, 0);
-            MZ_MFMA(3, 0);
-            MZ_FENCE();
-            na[0] = lds_frag(lds + nbuf + waddr[0]);
-            MZ_FENCE();
-            dma_piece(ring_m0 + ((ss + 3) & 3) * WSTAGE_BYTES, wt + ss * 512, lane_off);   // stage st + 3 -> the buffer stage st - 1 left
-            // the addresses of stage st + 1 (next channel quarter, or the next tap's first)
-            if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
-            set_kq((ss + 1) & 3);
-            MZ_FENCE();
-            // j = 1
-            MZ_MFMA(0, 1);
-            MZ_MFMA(1, 1);
-            MZ_FENCE();
-            b[0] = bfrag(0);
-            MZ_FENCE();
-            MZ_MFMA(2, 1);
-            MZ_MFMA(3, 1);
-            MZ_FENCE();
-            na[1] = lds_frag(lds + nbuf + waddr[1]);
-            MZ_FENCE();
-            // j = 2
-            MZ_MFMA(0, 2);
-            MZ_MFMA(1, 2);
-            MZ_FENCE();
-            b[1] = bfrag(1);
-            MZ_FENCE();
-            MZ_MFMA(2, 2);
-            MZ_MFMA(3, 2);
-            MZ_FENCE();
-            na[2] = lds_frag(lds + nbuf + waddr[2]);
-            MZ_FENCE();
-            // j = 3
-            MZ_MFMA(0, 3);
-            MZ_MFMA(1, 3);
-            MZ_FENCE();
-            b[2] = bfrag(2);
-            MZ_FENCE();
-            MZ_MFMA(2, 3);
-            MZ_MFMA(3, 3);
-            MZ_FENCE();
-            na[3] = lds_frag(lds + nbuf + waddr[3]);
-            MZ_FENCE();
-#undef MZ_MFMA
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[0], b[j & 3], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[1], b[j & 3], acc[1][j], 0, 0, 0);
+                MZ_FENCE();
+                b[(j + 3) & 3] = bfrag((j + 3) & 7);   // j <= 4: this stage's tile j + 3; j >= 5: the next stage's tile j - 5 (its addresses are set behind j = 4)
+                MZ_FENCE();
+                acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[2], b[j & 3], acc[2][j], 0, 0, 0);
+                acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[3], b[j & 3], acc[3][j], 0, 0, 0);
+                MZ_FENCE();
+                if (j < 4) {
+                    na[j] = lds_frag(lds + nbuf + waddr[j]);
+                    MZ_FENCE();
+                }
+                if (j == 0) {   // stage st + 3 -> the buffer stage st - 1 left
+                    if (ss < 9) {
+                        dma_piece(ring_m0 + ((ss + 3) & 3) * WSTAGE_BYTES, wt + ss * 512, lane_off);
+                    } else {   // stages 36..38 of the layer: the next layer's first stages, or (tail) the last convolution's 20 KB
+                        const uint4 *src = tail ? w_last + (ss - 9) * 512 : wt + ss * 512;
+                        if (ss < 11 || !tail || w < (LAST_W_BYTES - 2 * WSTAGE_BYTES) / 1024)
+                            dma_piece(ring_m0 + ((ss + 3) & 3) * WSTAGE_BYTES, src, lane_off);
+                    }
+                    MZ_FENCE();
+                }
+                if (j == 4) {   // the addresses of stage st + 1 (next channel quarter, or the next tap's first)
+                    if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
+                    set_kq((ss + 1) & 3);
+                    MZ_FENCE();
+                }
+            }
 #undef MZ_FENCE
         }
     }
 
     MZ_STAMP(tw, stamp_id);
-    // every wave is through its MFMAs (so through its reads of the source image and of the ring) before anything below
-    // writes the destination image: with RES the destination is read too, and dst may be what another wave's "tap 9"
-    // prefetch is still reading -- harmless for values, but the epilogue's own reads must see the image before any write to
-    // it only where they alias their own cells (they do: each lane reads and writes its own 8 bytes).  The stage-35 MFMAs
-    // of EVERY wave must be issued before T is overwritten by the last layer's weights (tail_dma): that needs a barrier.
-    // behind the last mid layer: the LAST conv layer's weights (20 KB, already in LDS order) go into the T image by
-    // LDS-DMA now, under this epilogue.  T is free once every wave has read its last fragments of it.
-    if (tail_dma) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the next layer's bias in the accumulator layout: channels cobase + 16 i + 4 kc + 0..3
+    f32x4 bn[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int piece = w + 8 * k;   // 1 KB pieces, wave-uniform
-            if (piece < LAST_W_BYTES / 1024) dma_piece(wave_lds_addr(lds, OFF_T + 8192 * k, tid), tail_dma + 8 * k * 64, lane_off);
-        }
-    }
-    // the next layer's bias: two thousand cycles of epilogue ahead of its first use
-    if (bias_next) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(bias_next + cobase + 16 * i + 4 * kc);
-    }
+    for (int i = 0; i < 4; ++i) bn[i] = bias_next ? *reinterpret_cast<const f32x4 *>(bias_next + cobase + 16 * i + 4 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // in place: every wave must be through its reads of the image (the "tap 9" prefetches included) before any cell changes
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // epilogue: lane = position, the 4 registers of a tile = channels co0 .. co0 + 3
-    char *dst = lds + dst_off;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
         const int q = posbase + 16 * j + p16;
-        char *row = dst + q * 256 + (kc & 1) * 8;
+        char *row = lds + OFF_X + q * 256 + (kc & 1) * 8;
         const int key = act_key(q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int chunk = (cobase >> 3) + 2 * i + (kc >> 1);   // co0 = cobase + 16 i + 4 kc
             char *p = row + ((chunk ^ key) << 4);
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
-            if (RES) {
-                const uint2 xr = *reinterpret_cast<const uint2 *>(p);
-                v[0] += bf16_up(xr.x & 0xFFFFu);
-                v[1] += bf16_up(xr.x >> 16);
-                v[2] += bf16_up(xr.y & 0xFFFFu);
-                v[3] += bf16_up(xr.y >> 16);
-            }
+            uint2 xr = make_uint2(0u, 0u);
+            if (MODE == 0) xr = *reinterpret_cast<const uint2 *>(p);   // x, before t overwrites it
             uint2 o;   // round, then ReLU on the packed bf16 pair (same result as ReLU then round: rounding keeps the sign)
-            o.x = relu_bf16x2(pack_bf16(v[0], v[1]));
-            o.y = relu_bf16x2(pack_bf16(v[2], v[3]));
+            o.x = relu_bf16x2(pack_bf16(acc[i][j][0], acc[i][j][1]));
+            o.y = relu_bf16x2(pack_bf16(acc[i][j][2], acc[i][j][3]));
             *reinterpret_cast<uint2 *>(p) = o;
+            if (MODE == 0)   // the second convolution of the block accumulates onto x + its bias
+                acc[i][j] = acc16_t{bf16_up(xr.x & 0xFFFFu) + bn[i][0], bf16_up(xr.x >> 16) + bn[i][1], bf16_up(xr.y & 0xFFFFu) + bn[i][2],
+                                    bf16_up(xr.y >> 16) + bn[i][3]};
+            else
+                acc[i][j] = bn[i];
         }
     }
-    // raw barrier (LDS only): the weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 and are
-    // retired by its first counted waits; __syncthreads() would stall every layer boundary on them
+    // raw barrier (LDS only): the weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 (or are the last
+    // convolution's weights) and are retired by the next counted waits; __syncthreads() would stall every layer boundary on them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// ---- first layer: input planes (global, NCHW) -> X.  Uses the T region as scratch: [256 pos][16 ch]
-// input image at OFF_T, all 9 tap weight slabs [9][128 co][16 ci] behind it. ---------------------------
+// ---- first layer: input planes (global, NCHW) -> the image.  Its operands are staged INSIDE the (not yet written) image:
+// [512 pos][16 ch] input at OFF_FIN, all 9 tap weight slabs [9][128 co][16 ci] at OFF_FW; the layer's whole output waits in
+// the accumulators (wave = 64 co x 128 positions = 2 x 4 tiles of 32 x 32) until every wave has read its operands. --------
 __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const uint16_t *__restrict__ x, int64_t board0, int64_t n_boards, int tid,
                                             uint32_t vm) {
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);
-    char *in = lds + OFF_T;
-    char *wf = lds + OFF_T + TILE_POS * 32;
+    const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
+    char *in = lds + OFF_FIN;
+    char *wf = lds + OFF_FW;
     f32x4 bv[2][4];   // requested now; the accumulators start at the bias (D rows of a 32x32 tile: 8 g + 4 h + k)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -379,47 +340,47 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
             bv[i][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (tw.b_first) bv[i][g] = *reinterpret_cast<const f32x4 *>(tw.b_first + cobase + 32 * i + 8 * g + 4 * h);
         }
-    {   // input: thread -> position tid & 255, channels 8*(tid >> 8) .. +7
-        const int q = tid & 255, part = tid >> 8;
+    {   // input: thread -> position tid, channels 0..15
+        const int q = tid;
         const int64_t b = board0 + (q >> 6);
-        uint32_t pk[4] = {0, 0, 0, 0};
-        if (b < n_boards && !(MZ_DIAG & 1)) {
+        uint32_t pk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (b < n_boards) {
             const uint16_t *px = x + b * tw.cin * 64 + (q & 63);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int c = part * 8 + k;
-                const uint32_t v = c < tw.cin ? (uint32_t)px[c * 64] : 0u;
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t v = k < tw.cin ? (uint32_t)px[k * 64] : 0u;
                 pk[k >> 1] |= v << ((k & 1) * 16);
             }
         }
-        *reinterpret_cast<uint4 *>(in + q * 32 + part * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        if (!(MZ_DIAG & 2))
-            for (int i = tid; i < FIRST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wf + i * 16) = tw.w_first[i];
+        *reinterpret_cast<uint4 *>(in + q * 32) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4 *>(in + q * 32 + 16) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        for (int i = tid; i < FIRST_W_BYTES / 16; i += 512) *reinterpret_cast<uint4 *>(wf + i * 16) = tw.w_first[i];
     }
     __syncthreads();
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = bv[i][k >> 2][k & 3];
 #pragma unroll
-    for (int tap = 0; tap < ((MZ_DIAG & 4) ? 0 : 9); ++tap) {
+    for (int tap = 0; tap < 9; ++tap) {
         const int dq = (tap / 3 - 1) * 8 + (tap % 3 - 1);
-        bf16x8 a[2], b[2];
+        bf16x8 a[2], b[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) a[i] = lds_frag(wf + (tap * 128 + cobase + 32 * i + r) * 32 + h * 16);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q2 = (posbase + 32 * j + r + dq) & 255;
-            b[j] = lds_frag(lds + (((vm >> (tap * 2 + j)) & 1u) ? OFF_T + q2 * 32 : OFF_Z) + h * 16);
+        for (int j = 0; j < 4; ++j) {   // 32-position tile j = rows 4 (j & 1) .. + 3 of board j >> 1
+            const int q2 = (posbase + 32 * j + r + dq) & 511;
+            b[j] = lds_frag(lds + (((vm >> (tap * 2 + (j & 1))) & 1u) ? OFF_FIN + q2 * 32 : OFF_Z) + h * 16);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    __syncthreads();   // every wave has read its operands: the image may be written over them
     char *dst = lds + OFF_X;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -427,13 +388,13 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
         for (int g = 0; g < 4; ++g) {
             const int co0 = cobase + 32 * i + 8 * g + 4 * h;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int q = posbase + 32 * j + r;
                 char *p = dst + q * 256 + ((((co0 >> 3) ^ act_key(q))) << 4) + h * 8;
                 uint2 o;   // round, then ReLU on the packed pair (as layer_mid)
                 o.x = relu_bf16x2(pack_bf16(acc[i][j][4 * g], acc[i][j][4 * g + 1]));
                 o.y = relu_bf16x2(pack_bf16(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
-                if (!(MZ_DIAG & 8) || o.x == 0x12345678u) *reinterpret_cast<uint2 *>(p) = o;
+                *reinterpret_cast<uint2 *>(p) = o;
             }
         }
     // the weight prologue's DMA pieces (mid_prologue: inline asm, invisible to the compiler's own waits) have landed too
@@ -470,102 +431,109 @@ __device__ __forceinline__ float heads_param(const Heads &hd, int tid) {
     return pv;
 }
 
-// ---- last layer: X -> hidden (8 planes), with the nine taps in the M dimension -------------------------------------------
-//   P[tap * 8 + plane][pos] = sum_ci W[tap][plane][ci] * X[pos][ci]        one GEMM, M = 72 (padded 80), N = 256, K = 128
+// ---- last layer: image -> hidden (8 planes), with the nine taps in the M dimension ---------------------------------------
+//   P[tap * 8 + plane][pos] = sum_ci W[tap][plane][ci] * X[pos][ci]        one GEMM, M = 72 (padded 80), N = 512, K = 128
 //   hidden[plane][pos]      = relu(b[plane] + sum_tap P[tap * 8 + plane][pos + shift(tap)])     (positions off the board: 0)
 // With the taps in K (as the mid layers have them) a 16-row MFMA tile would carry 8 real rows and every activation row would
-// be fetched from LDS nine times; here each wave reads its 32 positions ONCE (8 fragments) and all 20 weight fragments
-// (28 ds_read_b128 instead of 108, 40 MFMAs instead of 72), writes its 72 x 32 block of fp32 partial sums to LDS, and after
-// one barrier every thread sums the nine shifted taps of one position x four planes.  The layer was LDS-bandwidth bound.
-//   LDS: weights [4 quarters][80 rows][32 ci] at OFF_T (sent there by LDS-DMA under the last mid epilogue); P at OFF_P as
-//   [tap][plane half][pos][4 planes] fp32 (16-byte entries: conflict-free for the writers and the readers).
-// Output: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3 in hv[0..3] (what store_hidden writes and the heads read).
+// be fetched from LDS nine times; here wave w reads the 64 positions of board w ONCE (16 fragments) and the 20 weight
+// fragments, and holds its 72 x 64 block of fp32 partial sums in registers.  Behind one barrier (image and ring are dead then)
+// it writes them to LDS -- 18 KB per wave, private: a tap's shift stays inside the board -- and every lane sums the nine
+// shifted taps of one cell x eight planes.  No barrier between the writes and the reads: the LDS serves a wave in order.
+//   LDS: weights [4 quarters][80 rows][32 ci] in ring buffers 0..2 (sent there as the last K loop's "stages 36..38");
+//   P of wave w at w * P_WAVE_BYTES as [tap][plane half][cell][4 planes] fp32 (16-byte entries: conflict-free both ways).
+// Output: lane -> cell of board w, planes 0..7 in hv[0..7] (what store_hidden writes and the heads read).
 template <int OUT_DT>
-__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, float (&hv)[4]) {
+__device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, float (&hv)[8]) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
-    const char *wl = lds + OFF_T;
-    float *P = reinterpret_cast<float *>(lds + OFF_P);
-    static_assert(OFF_P + 9 * 2 * 256 * 16 <= LDS_BYTES, "the partial sums fit behind the last layer's weights");
-    // the weights were sent to T during the last mid layer's epilogue (layer_mid, tail_dma): retire every wave's pieces
+    const char *wl = lds + OFF_W;
+    float *P = reinterpret_cast<float *>(lds + w * P_WAVE_BYTES);
+    // retire every wave's DMA pieces of the weights
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    bf16x8 bf[2][4];
+    bf16x8 bf[4][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = 32 * w + 16 * j + p16;
+    for (int j = 0; j < 4; ++j) {
+        const int q = 64 * w + 16 * j + p16;
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) bf[j][kq] = lds_frag(lds + OFF_X + q * 256 + (((4 * kq + kc) ^ act_key(q)) << 4));
     }
-    acc16_t acc[5][2];
+    acc16_t acc[5][4];
 #pragma unroll
-    for (int m = 0; m < ((MZ_DIAG & 32) ? 0 : 5); ++m) {
+    for (int m = 0; m < 5; ++m) {
         const int row = 16 * m + c16;
         const int waddr = row * 64 + ((kc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 4);
         bf16x8 af[4];
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) af[kq] = lds_frag(wl + kq * (LAST_ROWS * 64) + waddr);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
             acc[m][j] = acc16_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int kq = 0; kq < 4; ++kq) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kq], bf[j][kq], acc[m][j], 0, 0, 0);
         }
     }
-    // D: lane -> position (its column), rows 16 m + 4 kc + 0..3 = tap 2 m + (kc >> 1), planes 4 (kc & 1) + 0..3
+    // every wave holds its fragments in registers: the image and the ring may be overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // D: lane -> cell (its column), rows 16 m + 4 kc + 0..3 = tap 2 m + (kc >> 1), planes 4 (kc & 1) + 0..3
 #pragma unroll
-    for (int m = 0; m < ((MZ_DIAG & 32) ? 0 : 5); ++m) {
+    for (int m = 0; m < 5; ++m) {
         const int tap = 2 * m + (kc >> 1);
         if (tap < 9) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int q = 32 * w + 16 * j + p16;
-                *reinterpret_cast<f32x4 *>(P + ((tap * 2 + (kc & 1)) * 256 + q) * 4) = f32x4{acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+            for (int j = 0; j < 4; ++j) {
+                const int q = 16 * j + p16;
+                *reinterpret_cast<f32x4 *>(P + ((tap * 2 + (kc & 1)) * 64 + q) * 4) = f32x4{acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
             }
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    {   // gather the nine shifted taps: thread -> position q, plane half h
-        const int q = tid & 255, h = tid >> 8, x = q & 7, y = (q >> 3) & 7;
-        f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (tw.b_last) sum = *reinterpret_cast<const f32x4 *>(tw.b_last + 4 * h);
+    {   // gather the nine shifted taps: lane -> cell q of board w, both plane halves
+        const int q = lane, x = q & 7, y = q >> 3;
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (tw.b_last) {
+            s0 = *reinterpret_cast<const f32x4 *>(tw.b_last);
+            s1 = *reinterpret_cast<const f32x4 *>(tw.b_last + 4);
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
             const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(y + ky - 1) < 8u;
-            const int q2 = (q + (ky - 1) * 8 + (kx - 1)) & 255;
-            const f32x4 pv = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + h) * 256 + q2) * 4);
-            if (ok) sum += pv;
+            const int q2 = (q + (ky - 1) * 8 + (kx - 1)) & 63;
+            const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + 0) * 64 + q2) * 4);
+            const f32x4 p1 = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + 1) * 64 + q2) * 4);
+            if (ok) {
+                s0 += p0;
+                s1 += p1;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float v = fmaxf(sum[k], 0.0f);
+        for (int k = 0; k < 8; ++k) {
+            const float v = fmaxf(k < 4 ? s0[k & 3] : s1[k & 3], 0.0f);
             hv[k] = OUT_DT == MZ_F32 ? v : bf16_up(bf16_rne(v));   // what store_hidden writes (and the heads read back)
         }
     }
-    // every wave is done with the X image, the last layer's weights and P: whatever comes next (the heads, or the next
-    // tile's first layer and weight prologue) may overwrite them
+    // every wave is done with its partial sums: whatever comes next (the heads, or the next tile's first layer and weight
+    // prologue) may overwrite them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// the hidden state (global, NCHW, 8 planes) from layer_last's registers: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3;
-// consecutive lanes write consecutive cells of one plane.  Nothing in the kernel waits on these stores.
+// the hidden state (global, NCHW, 8 planes) from layer_last's registers: wave -> board, lane -> cell; consecutive lanes write
+// consecutive cells of one plane.  Nothing in the kernel waits on these stores.
 template <int OUT_DT>
-__device__ __forceinline__ void store_hidden(const float (&hv)[4], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
-    const int q = tid & 255, h = tid >> 8;
-    const int64_t b = board0 + (q >> 6);
-    if (b >= n_boards || (MZ_DIAG & 64)) return;
+__device__ __forceinline__ void store_hidden(const float (&hv)[8], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
+    const int64_t b = board0 + (tid >> 6);
+    if (b >= n_boards) return;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t o = b * 512 + (4 * h + k) * 64 + (q & 63);
+    for (int k = 0; k < 8; ++k) {
+        const int64_t o = b * 512 + k * 64 + (tid & 63);
         if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = hv[k];
         else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)(__float_as_uint(hv[k]) >> 16);
     }
 }
 
-// ---- prediction heads (network.py:79-111) for a BATCH of up to 4 tiles = 16 boards of this workgroup ---------------------
+// ---- prediction heads (network.py:79-111) for a BATCH of up to 2 tiles = 16 boards of this workgroup ---------------------
 // Run once per tile on the VALU the heads cost 8.6k cycles of an otherwise matrix-bound kernel, and that cost is arithmetic
 // (4 x 25k fp32 MACs + bf16 unpacking per tile; batching alone bought nothing).  Sixteen boards are exactly one MFMA column
-// tile, so the persistent workgroup runs the heads once per FOUR tiles, on the hidden states it stored itself (slot s of the
-// batch = board s & 3 of tile tile0 + (s >> 2) * tstride), with both Linear layers on v_mfma_f32_16x16x32_bf16:
+// tile, so the persistent workgroup runs the heads once per TWO tiles, on the hidden states it stored itself (slot s of the
+// batch = board s & 7 of tile tile0 + (s >> 3) * tstride), with both Linear layers on v_mfma_f32_16x16x32_bf16:
 //   D[out][board] = sum_in W[out][in] * f[in][board],  A = weights (bf16, exact), B = features.
 // The features are fp32 (1x1 conv + ReLU outputs); each goes in as TWO bf16 terms, hi = bf16(f) and lo = bf16(f - hi), two
 // MFMAs per k-step into one fp32 accumulator: 16 significant bits of f survive, products are exact, sums are fp32 -- within
@@ -603,13 +571,13 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// The hidden states of the batch's EARLIER tiles come back from global memory (this workgroup stored them, store_hidden, at
-// least one whole tile ago); the loads are issued before the last tile's last layer and land under its MFMAs.  They bypass the
+// The hidden states of the batch's EARLIER tile come back from global memory (this workgroup stored them, store_hidden, a
+// whole tile ago); the loads are issued before the last tile's last layer and land under its MFMAs.  They bypass the
 // CU's L1 (agent-scope relaxed atomic load = global_load sc1).  The batch's last tile hands its values over in registers.
 template <int OUT_DT>
 struct Readback {
     static constexpr int NW = OUT_DT == MZ_F32 ? 512 : 256;   // dwords per board
-    static constexpr int R = 12 * NW / 512;                   // dwords per thread for 3 earlier tiles = 12 boards
+    static constexpr int R = 8 * NW / 512;                    // dwords per thread for the earlier tile = 8 boards
     uint32_t v[R];
     float pv;   // this thread's small head parameter (heads_param), requested with the readback
 };
@@ -620,15 +588,15 @@ __device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads
 #pragma unroll
     for (int r = 0; r < Readback<OUT_DT>::R; ++r) {
         const int i = tid + 512 * r, slot = i / NW;
-        const int sl = slot < 4 * nprev ? slot : 0;    // unused slots re-read the batch's first board (valid) and are ignored later
-        const int64_t b = (tile0 + (int64_t)(sl >> 2) * tstride) * TILE_BOARDS + (sl & 3);
+        const int sl = slot < 8 * nprev ? slot : 0;    // unused slots re-read the batch's first board (valid) and are ignored later
+        const int64_t b = (tile0 + (int64_t)(sl >> 3) * tstride) * TILE_BOARDS + (sl & 7);
         rb.v[r] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(hidden) + b * NW + (i % NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     rb.pv = heads_param(hd, tid);
 }
 
 template <int OUT_DT>
-__device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Readback<OUT_DT> &rb, const float (&hv)[4], int64_t n_boards,
+__device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Readback<OUT_DT> &rb, const float (&hv)[8], int64_t n_boards,
                                             int64_t tile0, int64_t tstride, int ntiles, int tid, long long *stamps) {
 #define MZ_HSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = (long long)__builtin_readcyclecounter(); } while (0)
     float *hid = reinterpret_cast<float *>(lds);
@@ -643,21 +611,20 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
     static_assert(59392 + (HB + 512) * 4 <= ACT_BYTES && HB * FROW * 2 <= 4608, "the heads stay inside the X image region");
     const int w = tid >> 6, lane = tid & 63, n16 = lane & 15, kc = lane >> 4;
     const int grp = tid >> 7, k = tid & 127;
-    const int nb = 4 * ntiles;                 // slots in use
-    auto board_of = [&](int s) { return (tile0 + (int64_t)(s >> 2) * tstride) * TILE_BOARDS + (s & 3); };
+    const int nb = 8 * ntiles;                 // slots in use
+    auto board_of = [&](int s) { return (tile0 + (int64_t)(s >> 3) * tstride) * TILE_BOARDS + (s & 7); };
     MZ_HSTAMP(19);
-    if (MZ_DIAG & 128) return;   // (diagnostic)
     // no barrier needed before these LDS writes: layer_last ended with one, and nothing has touched LDS since
-    {   // earlier tiles: the readback registers; unused slots are zero-filled
+    {   // earlier tile: the readback registers; unused slots are zero-filled
         constexpr int NW = Readback<OUT_DT>::NW;
 #pragma unroll
         for (int r = 0; r < Readback<OUT_DT>::R; ++r) {
             const int i = tid + 512 * r;
-            const uint32_t v = (i / NW) < nb - 4 ? rb.v[r] : 0u;
+            const uint32_t v = (i / NW) < nb - 8 ? rb.v[r] : 0u;
             if (OUT_DT == MZ_F32) hid[i] = __uint_as_float(v);
             else *reinterpret_cast<float2 *>(hid + 2 * i) = make_float2(bf16_up(v & 0xFFFFu), bf16_up(v >> 16));
         }
-        for (int i = 12 * 512 + tid; i < HB * 512; i += 512) hid[i] = 0.0f;   // slots 12..15 (overwritten below when the batch is full)
+        for (int i = 8 * 512 + tid; i < HB * 512; i += 512) hid[i] = 0.0f;   // slots 8..15 (overwritten below when the batch is full)
     }
     // every global read of the heads' weights is requested here, BEHIND the staging above (the memory queue is in order: a
     // wait for the readback must not also wait for these); the matrices are consumed two phases later
@@ -665,11 +632,10 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
     heads_prefetch(hd, tid, hr);
     prm[tid] = rb.pv;
     __syncthreads();
-    {   // the batch's last tile, from layer_last's registers: thread -> position tid & 255, planes 4 (tid >> 8) + 0..3
-        const int q = tid & 255, h = tid >> 8;
-        float *dst = hid + (nb - 4 + (q >> 6)) * 512 + (q & 63);
+    {   // the batch's last tile, from layer_last's registers: wave -> board, lane -> cell, planes 0..7
+        float *dst = hid + (nb - 8 + w) * 512 + lane;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) dst[(4 * h + k) * 64] = hv[k];
+        for (int k = 0; k < 8; ++k) dst[k * 64] = hv[k];
     }
     __syncthreads();
     MZ_HSTAMP(21);
@@ -770,10 +736,10 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
     // first layer's own __syncthreads()
 }
 
-// one 4-board tile through the convolution tower: first layer, three residual blocks, last layer, hidden state stored
+// one 8-board tile through the convolution tower: first layer, three residual blocks, last layer, hidden state stored
 template <int OUT_DT>
 __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const Heads &hd, const uint16_t *__restrict__ x, void *__restrict__ hidden,
-                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[4]) {
+                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[8]) {
     Tower tw = tw_;
     if (tw.stamps) tw.stamps += tile * 24;   // this tile's row of the diagnostics array
     const uint32_t vm = halo_mask(tid & 31);
@@ -787,14 +753,18 @@ __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const He
     layer_first(lds, tw, x, board0, n_boards, tid, vm);
     MZ_STAMP(tw, 1);
     MZ_STAMP(tw, 2);
+    acc16_t acc[4][8];   // the K loops' accumulators: each layer's epilogue leaves the next layer's starting values in them
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = bv[i];
 #pragma unroll 1
     for (int blk = 0; blk < 3; ++blk) {
         const uint4 *w0 = tw.w_mid + (int64_t)(2 * blk) * N_STAGES * 512;
         const uint4 *w1 = tw.w_mid + (int64_t)(2 * blk + 1) * N_STAGES * 512;
-        layer_mid<false>(lds, OFF_X, OFF_T, w0, bv, tw.b_mid + (2 * blk + 1) * 128, nullptr, tid, vm, tw, 3 + 4 * blk);      // t = relu(conv(x))
+        layer_mid<0>(lds, w0, nullptr, acc, tw.b_mid + (2 * blk + 1) * 128, tid, tw, 3 + 4 * blk);                       // t = relu(conv(x)); acc = x + bias
         MZ_STAMP(tw, 4 + 4 * blk);
-        layer_mid<true>(lds, OFF_T, OFF_X, w1, bv, blk < 2 ? tw.b_mid + (2 * blk + 2) * 128 : nullptr, blk == 2 ? tw.w_last : nullptr, tid, vm, tw,
-                         5 + 4 * blk);   // x = relu(x + conv(t))
+        layer_mid<1>(lds, w1, blk == 2 ? tw.w_last : nullptr, acc, blk < 2 ? tw.b_mid + (2 * blk + 2) * 128 : nullptr, tid, tw, 5 + 4 * blk);   // x = relu(x + conv(t))
         MZ_STAMP(tw, 6 + 4 * blk);
     }
     asm volatile("" : "+v"(tid));   // lane-derived addresses of the phases below are computed HERE, not held across the K loops
@@ -839,11 +809,11 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
                        karg<const float *>(ka, offsetof(KArgs, hd.vc_w)),    karg<const float *>(ka, offsetof(KArgs, hd.vc_b)),
                        karg<const float *>(ka, offsetof(KArgs, hd.v1_w)),    karg<const float *>(ka, offsetof(KArgs, hd.v1_b)),
                        karg<float *>(ka, offsetof(KArgs, hd.value)),         karg<float *>(ka, offsetof(KArgs, hd.policy))};
-        // the heads run once per batch of four tiles (heads_batch): after this tile if it is the batch's fourth or the workgroup's last
-        const bool heads_now = hd.policy != nullptr && (in_batch == 3 || (tile + gridDim.x) * TILE_BOARDS >= n_boards);
+        // the heads run once per batch of two tiles (heads_batch): after this tile if it is the batch's second or the workgroup's last
+        const bool heads_now = hd.policy != nullptr && (in_batch == 1 || (tile + gridDim.x) * TILE_BOARDS >= n_boards);
         void *hidden = karg<void *>(ka, offsetof(KArgs, hidden));
         Readback<OUT_DT> rb;
-        float hv[4];
+        float hv[8];
         tower_tile<OUT_DT>(lds, tw, hd, karg<const uint16_t *>(ka, offsetof(KArgs, x)), hidden, n_boards, tile, tid, rb, heads_now ? in_batch : -1, gridDim.x, hv);
         ++in_batch;
         if (heads_now) {

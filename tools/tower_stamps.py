@@ -15,7 +15,7 @@ while time.time() - t0 < 2.0:   # the clock the chip holds under sustained load 
     for _ in range(50):
         eng.recurrent(x)
     torch.cuda.synchronize()
-nb = (B + 3) // 4
+nb = (B + 7) // 8   # 8-board tiles
 st = torch.zeros((nb, 24), dtype=torch.int64, device="cuda")
 eng._packs["dyn"]["struct"].debug_stamps = st.data_ptr()
 eng.recurrent(x)
