@@ -92,15 +92,29 @@ def pmc_traffic(kernel):
     (doubled, MI355X_MICROARCH.md gfx950 correction) + WRITE_SIZE at this bench's launch shape.
     rocprofv3 cannot run inside this process, so the number is read from the newest committed profile of this
     same command (profiles/rNN/pmc_summary.json, regenerated every round); None when no profile is present."""
-    best = None
+    return pmc_traffic_src(kernel)[0]
+
+
+def newest_profile(name):
+    """path of the newest committed profiles/rNN/<name>, or None"""
     pdir = os.path.join(ROOT, "profiles")
-    for r in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+    for r in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, r, name)
+        if os.path.exists(f):
+            return f
+    return None
+
+
+def pmc_traffic_src(kernel):
+    """(bytes per launch, the committed file they were read from) -- the number is NOT measured in this run"""
+    pdir = os.path.join(ROOT, "profiles")
+    for r in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, r, "pmc_summary.json")
         if os.path.exists(f):
             rec = json.load(open(f)).get(kernel)
             if rec and rec.get("hbm_bytes_per_launch"):
-                best = rec["hbm_bytes_per_launch"]
-    return best
+                return rec["hbm_bytes_per_launch"], "profiles/%s/pmc_summary.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)" % r
+    return None, None
 
 
 def event_time_ms(fn, iters):
@@ -162,7 +176,7 @@ def bench_env(args, device):
         ms_big = step_kernel_ms(eb, big, 1 << 24, 1)
         g2 = big * ENV_BYTES_PER_STEP / (ms_big * 1e-3) / 1e9
         roof_big = {"kernel": "k_env_step", "games": big, "bound": "hbm", "achieved": g2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": g2 / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step_hbm"), "algorithmic_bytes_per_launch": big * ENV_BYTES_PER_STEP,
+                    "frac": g2 / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step_hbm"), "traffic_source": pmc_traffic_src("k_env_step_hbm")[1], "algorithmic_bytes_per_launch": big * ENV_BYTES_PER_STEP,
                     "us_per_launch": ms_big * 1e3, "env_steps_per_sec": big / (ms_big * 1e-3),
                     "working_set_bytes": big * 21, "note": "state exceeds L2 + Infinity Cache: served from HBM"}
         del eb
@@ -179,7 +193,7 @@ def bench_env(args, device):
         "env_steps_per_sec_fused_playout": n * 60 / (ms_fused * 1e-3),
         "env_steps_per_sec_step_kernel": n / (ms_step * 1e-3),
         "roofline_env": {"kernel": "k_env_step", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step"), "bytes_per_step": ENV_BYTES_PER_STEP,
+                         "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_env_step"), "traffic_source": pmc_traffic_src("k_env_step")[1], "bytes_per_step": ENV_BYTES_PER_STEP,
                          "algorithmic_bytes_per_launch": n * ENV_BYTES_PER_STEP, "us_per_launch": ms_step * 1e3,
                          "note": "nominal: the 1,048,576-game state (22 MB + actions) stays resident in L2 + Infinity Cache, so this is "
                                  "algorithmic bytes over time, not HBM traffic; the kernel is VALU-issue bound (valu) -- roofline_env_hbm is the HBM point",
@@ -297,12 +311,13 @@ def bench_cpu_baseline(args, roots, image, noise):
            "sample": "one search of %d trees x %d sims on the GPU leg's roots (positions after 0..59 moves, same noise): C oracle "
                      "(oracle/mz_oracle.c, one OpenMP call per simulation) + PyTorch CPU fp32 inference at batch %d, %.1f s" % (n, S, n, dt)}
     # the reference cannot run on the GPU box; its ratio to this port was measured with both on the
-    # build container's 8 cores (tools/cpu_ratio.py -> profiles/r02/cpu_ratio_container.json)
-    f = os.path.join(ROOT, "profiles", "r02", "cpu_ratio_container.json")
-    if os.path.exists(f):
+    # build container's 8 cores (tools/cpu_ratio.py -> profiles/rNN/cpu_ratio_container.json, the newest round's)
+    f = newest_profile("cpu_ratio_container.json")
+    if f:
         r = json.load(open(f))
         out["ratio_to_reference"] = r["port_sims_per_sec"] / r["reference_sims_per_sec"]
         out["reference_container"] = {k: r[k] for k in ("reference_sims_per_sec", "port_sims_per_sec", "cores", "workload")}
+        out["reference_container"]["source"] = os.path.relpath(f, ROOT)
     return out, tb.root_visits()
 
 
@@ -341,8 +356,12 @@ def main():
     eng.env = roots
     image = make_image(hw, hb, idx, n, dtype)
 
+    if eng._image.dtype == image.dtype:   # the engine's own image buffer: what play_games fills (no copy in front of the graph)
+        eng._image.copy_(image)
+        image = eng._image
+
     def step():
-        return eng.search(image)
+        return eng.search(image, copy=False)
 
     for _ in range(args.warmup):
         step()
@@ -416,7 +435,7 @@ def main():
         us = tot_ms / launches * 1e3
         gbps = n * (tree_bytes + hid_bytes) / (us * 1e-6) / 1e9
         out["roofline_tree"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "us_per_launch": us,
+                                "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "traffic_source": pmc_traffic_src("k_backup_select")[1], "us_per_launch": us,
                                 "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
                                 "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes),
                                 "share_of_step": us * 1e-3 / (dt / args.steps / S * 1e3),
@@ -450,7 +469,7 @@ def main():
         tf = flop / (ms_net * 1e-3) / 1e12
         out["roofline"] = {"kernel": "k_tower (mz_inference_forward: LDS-resident conv tower + prediction heads)" if hip else
                            "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf, "peak": peak,
-                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": pmc_traffic("k_tower") if hip else None,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": pmc_traffic("k_tower") if hip else None, "traffic_source": pmc_traffic_src("k_tower")[1] if hip else None,
                            "us_per_launch": ms_net * 1e3, "boards_per_launch": n, "flop_per_board": TOWER_FLOP if hip else NET_MFLOP * 1e6,
                            "algorithmic_flop_per_launch": flop, "share_of_step": ms_net / (dt / args.steps / S * 1e3)}
         out.update(bench_env(args, device))

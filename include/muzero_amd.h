@@ -130,7 +130,11 @@ typedef struct mz_search_cfg {
     int32_t negamax;     /* 0 = reference: ucb_score adds normalize(child.value()) (main.py:159), the value from the
                             CHILD's mover's point of view -- the two-player sign slip of the MuZero pseudocode: the search
                             prefers moves that are good for the opponent.  1 = normalize(-child.value()) (non-default) */
-    int32_t reserved;    /* 0 */
+    int32_t device_noise; /* 1: where a root expansion is given noise == NULL, draw np.random.dirichlet([noise_alpha] * n_children)
+                             (main.py:192-193) on the device from a counter-based stream keyed (noise_seed, tree, searches this
+                             tree slot has started); 0: NULL noise means no exploration noise (test.py's arena) */
+    double noise_alpha;   /* config.py:18 root_dirichlet_alpha */
+    uint64_t noise_seed;
 } mz_search_cfg;
 
 /* Node pool for n_trees independent searches of at most max_nodes-1 simulations each, laid out by
@@ -161,11 +165,14 @@ typedef struct mz_tree_meta {
     int32_t mm_flags;    /* bit0: minimum is an fp32 tensor, bit1: maximum is (else Python float) */
     int32_t path_len;    /* edges of the current simulation's path */
     int32_t leaf_player; /* player of the leaf of the current simulation */
-    int32_t error;       /* bit0: pool full; bit1: select without root */
+    int32_t error;       /* bit0: pool full; bit1: select without root; bit2 (MZ_TREE_ERR_POLICY_MASS): an expansion's policy mass over
+                            the expanded actions was 0 (the reference raises ZeroDivisionError, main.py:171-175) or not finite */
     int32_t leaf_parent; /* expanded-node id whose hidden state feeds recurrent_inference */
     int32_t leaf_action; /* history[-1].index */
-    int32_t pad[2];
+    int32_t pad[2];      /* pad[0]: searches this tree slot has started (mz_mcts_root_init counts; keys the device noise stream) */
 } mz_tree_meta;
+
+#define MZ_TREE_ERR_POLICY_MASS 4
 
 /* host-only: compute the layout (no device access). max_nodes in [2, 65534]. */
 int mz_pool_layout_compute(int32_t n_trees, int32_t max_nodes, int32_t hidden_dtype, mz_pool_layout *out);
@@ -255,6 +262,8 @@ typedef struct mz_replay {
     float *root_values; /* [window][max_moves]   Game.root_values */
     int32_t *length;    /* [window]              len(action_history) */
     int32_t window, max_moves;
+    int32_t *refused;   /* optional, may be NULL: device counter that mz_replay_sample_batch increments once per sample it
+                           refuses (slot or position outside the window / the game); the caller zeroes and reads it */
 } mz_replay;
 
 /* element type of the root visit counts in a trajectory record */
@@ -279,7 +288,9 @@ int mz_replay_save(const mz_replay *rb, int32_t slot0, const uint64_t *hist_whit
  *   image           (batch,9,8,8)    Game.make_image(position)                   utilities.py:88
  *   actions         (K,batch,2,8,8)  Action.encode of the K real moves           utilities.py:89,95
  *   target_values   (K+1,batch)      Game.make_target values                     reversi.py:331-338
- *   target_policies (K+1,batch,65)   Game.make_target policies (zeros past end)  reversi.py:335,339 */
+ *   target_policies (K+1,batch,65)   Game.make_target policies (zeros past end)  reversi.py:335,339
+ * A pair outside its game (slot outside the window, position < 0 or position + K > length) is a caller bug: the sample's rows
+ * are written as zeros -- never left uninitialised -- and rb->refused, when given, counts it. */
 int mz_replay_sample_batch(const mz_replay *rb, const int32_t *slot, const int32_t *pos, int32_t batch, int32_t K,
                            float *image, float *actions, float *target_values, float *target_policies, void *stream);
 
@@ -298,7 +309,7 @@ int mz_bias_act_nhwc(void *y, const void *bias, const void *residual, int64_t n_
  * Convolution tower (network.py:49-77 Representation, :113-135 Dynamics) as one LDS-resident MFMA
  * kernel: conv3x3 cin->128 + ReLU, three ResidualBlocks (network.py:35-47), conv3x3 128->8 + ReLU.
  * bf16 operands, fp32 accumulation, one bf16 rounding per layer output.  Activations never leave
- * LDS between layers (tower_kernels.hip); the prediction heads stay in PyTorch.
+ * LDS between layers (tower_kernels.hip: eight boards per workgroup, one activation image updated in place).
  * ---------------------------------------------------------------------------------------- */
 typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muzero_amd.network.pack_tower) */
     const void *w_first;   /* bf16 [9 taps][128 co][16 ci]      conv1 / dynamics conv.0, ci zero-padded; tap = ky*3+kx */
@@ -307,16 +318,18 @@ typedef struct mz_tower_weights {   /* device pointers to PREPACKED weights (muz
                               16-byte chunk c of the 32 input channels stored in slot c ^ {0,2,3,1}[(co >> 2) & 3];
                               followed by 4 stages (32 KB) of padding: the weight stream prefetches 4 stages ahead */
     const float *b_mid;    /* f32 [6][128] */
-    const void *w_last;    /* bf16 [4 quarters of ci][80 rows = tap * 8 + plane (rows 72..79 zero)][4 slots][8]: chunk swizzle as w_mid */
+    const void *w_last;    /* bf16 [4 quarters of ci][80 rows = tap * 8 + plane (rows 72..79 zero)][4 slots][8]: chunk swizzle as w_mid;
+                              20,480 bytes, read as the weight stream's last 2.5 stages */
     const float *b_last;   /* f32 [8] or NULL (network.py:127) */
     int32_t cin;           /* input planes: 9 (Representation) or 10 (Dynamics: hidden ++ action planes) */
-    int64_t *debug_stamps; /* diagnostics, normally NULL: device array [ceil(n/4)][24] receiving s_memtime stamps at the
+    int64_t *debug_stamps; /* diagnostics, normally NULL: device array [ceil(n/8)][24] receiving s_memtime stamps at the
                               kernel's phase boundaries (0 start, 1 first layer, 2 weight prologue, 3+2l / 4+2l K loop /
                               epilogue of mid layer l, 15 last layer, 16 heads) */
 } mz_tower_weights;
 
 /* x: (n,cin,8,8) bf16 NCHW (e.g. the net_in rows mz_mcts_select writes); hidden: (n,8,8,8) NCHW of
- * hidden_dtype (MZ_BF16 or MZ_F32).  One workgroup per 4 boards. */
+ * hidden_dtype (MZ_BF16 or MZ_F32).  Persistent grid, one workgroup per CU walking 8-board tiles.  All weight pointers
+ * 16-byte aligned. */
 int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream);
 
 /* Prediction heads (network.py:79-111) fused behind the tower: 1x1 conv 8->2 + ReLU + Flatten +
@@ -327,9 +340,9 @@ int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int
  * arithmetic.  Within 2e-5 of the fp32 module on the same hidden state. */
 typedef struct mz_heads_weights {
     const float *pc_w, *pc_b;   /* policy_head.0: [2][8], [2] */
-    const void *p1_w;           /* policy_head.3 weight: bf16 [128 out][128 in] */
+    const void *p1_w;           /* policy_head.3 weight: bf16 [128 out][128 in]; 16-byte aligned (fetched as 16-byte MFMA fragments) */
     const float *p1_b;          /* [128] */
-    const void *p2_w;           /* policy_head.5 weight: bf16 [65 out][128 in] */
+    const void *p2_w;           /* policy_head.5 weight: bf16 [65 out][128 in]; 16-byte aligned */
     const float *p2_b;          /* [65] */
     const float *vc_w, *vc_b;   /* value_head.0: [2][8], [2] */
     const float *v1_w, *v1_b;   /* value_head.3: [128], [1] */

@@ -25,7 +25,8 @@ class SearchCfg(C.Structure):
     """mz_search_cfg -- the config.py knobs the search reads (config.py:15,19,22,23,29)."""
     _fields_ = [("pb_c_base", C.c_double), ("pb_c_init", C.c_double), ("discount", C.c_double),
                 ("noise_frac", C.c_double), ("bound_lo", C.c_double), ("bound_hi", C.c_double),
-                ("bounds_none", C.c_int32), ("tie_lowest", C.c_int32), ("negamax", C.c_int32), ("reserved", C.c_int32)]
+                ("bounds_none", C.c_int32), ("tie_lowest", C.c_int32), ("negamax", C.c_int32), ("device_noise", C.c_int32),
+                ("noise_alpha", C.c_double), ("noise_seed", C.c_uint64)]
 
 
 class PoolLayout(C.Structure):
@@ -40,7 +41,7 @@ class Replay(C.Structure):
     """mz_replay -- device arrays of the replay window (host struct of device pointers)"""
     _fields_ = [("white", C.c_void_p), ("black", C.c_void_p), ("actions", C.c_void_p), ("rewards", C.c_void_p),
                 ("policy", C.c_void_p), ("root_values", C.c_void_p), ("length", C.c_void_p),
-                ("window", C.c_int32), ("max_moves", C.c_int32)]
+                ("window", C.c_int32), ("max_moves", C.c_int32), ("refused", C.c_void_p)]
 
 
 class TowerWeights(C.Structure):

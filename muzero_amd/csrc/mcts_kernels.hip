@@ -209,9 +209,16 @@ __device__ __forceinline__ void copy_hidden(char *dst, const char *src, int elem
 
 // expand_node main.py:165-175: priors over the masked actions, policy_sum sequential in double in
 // ascending action order (H3).  Writes the 65 child records of `node`.
+// the reference divides Python floats (main.py:171-175: .item(), then p / policy_sum): a policy mass of exactly 0.0 over the
+// expanded actions raises ZeroDivisionError there.  Here the division yields NaN priors (which select_argmax treats as Python's
+// max() treats NaN scores) and the tree's error word gets MZ_TREE_ERR_POLICY_MASS, as it does for a non-finite mass (NaN / inf
+// network outputs: no exception in the reference, but nothing a search should go on with): callers raise on it (selfplay.py).
+__device__ __forceinline__ bool bad_policy_mass(double sum) { return !(sum != 0.0) || !(fabs(sum) < (double)INFINITY); }
+
+// Returns the policy mass it divided by.
 template <bool ALL>
-__device__ __forceinline__ void write_children(const Pool &P, int64_t node_row, const float *policy, uint64_t mask, bool pass_ok,
-                                               const double *noise, double frac, int lane) {
+__device__ __forceinline__ double write_children(const Pool &P, int64_t node_row, const float *policy, uint64_t mask, bool pass_ok,
+                                                 bool with_noise, double nz, double nz64, double frac, int lane) {
     const float p = policy[lane], p64 = policy[64];
     double sum = 0.0;
 #pragma unroll
@@ -223,12 +230,65 @@ __device__ __forceinline__ void write_children(const Pool &P, int64_t node_row, 
     ChildRec *recs = P.stats + node_row * MZ_ACTIONS;
     const bool ex = ALL || ((mask >> lane) & 1ULL);
     double prior = (double)p / sum, prior64 = (double)p64 / sum;
-    if (noise) {  // add_exploration_noise main.py:191-196
-        prior = prior * (1 - frac) + noise[lane] * frac;
-        prior64 = prior64 * (1 - frac) + noise[64] * frac;
+    if (with_noise) {  // add_exploration_noise main.py:191-196 (nz: this lane's action, nz64: the pass action)
+        prior = prior * (1 - frac) + nz * frac;
+        prior64 = prior64 * (1 - frac) + nz64 * frac;
     }
     recs[lane] = ex ? ChildRec{0u, 0.0f, prior} : ChildRec{NOT_CHILD, 0.0f, 0.0};
     if (lane == 0) recs[64] = (ALL || pass_ok) ? ChildRec{0u, 0.0f, prior64} : ChildRec{NOT_CHILD, 0.0f, 0.0};
+    return sum;
+}
+
+// ---- np.random.dirichlet([alpha] * n_children) (main.py:192-193) drawn on the device, by action -----------------------------
+// The reference draws from numpy's global generator, which nothing seeds: any generator with the right law serves.
+// Here: a counter-based stream keyed (cfg.noise_seed, tree, number of searches this tree slot has started), so a search is
+// reproducible from the seed and the count, needs no generator state in memory and can sit in a captured graph.
+// Gamma(alpha) per child by Marsaglia-Tsang on shape alpha + 1 times U^(1/alpha) (alpha < 1), kept as a LOGARITHM: at
+// alpha = 0.03 most draws underflow a double (U^33), and the normalisation only needs differences to the largest.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {   // splitmix64's finaliser (as env_kernels.hip)
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t key, uint32_t draw) {   // uniform in (0, 1), 53 bits
+    return ((double)(mix64(key + (uint64_t)draw * 0xD1342543DE82EF95ULL) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double log_gamma_draw(double alpha, uint64_t key) {
+    const double a = alpha < 1.0 ? alpha + 1.0 : alpha, d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double g = d;   // (32 rejections in a row: probability < 1e-40)
+    for (uint32_t it = 0; it < 32; ++it) {
+        const double u1 = u01(key, 4 * it), u2 = u01(key, 4 * it + 1), u3 = u01(key, 4 * it + 2);
+        const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        if (log(u3) < 0.5 * x * x + d - d * v + d * log(v)) {
+            g = d * v;
+            break;
+        }
+    }
+    double lg = log(g);
+    if (alpha < 1.0) lg += log(u01(key, 0xFFFFFFFFu)) / alpha;
+    return lg;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {   // (once per search: the shuffle form will do)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// -> nz (this lane's action) and nz64 (the pass action): a Dirichlet(alpha, ..., alpha) sample over the root's children
+__device__ __forceinline__ void device_dirichlet(double alpha, uint64_t seed, int t, uint32_t n_search, uint64_t mask, bool pass, int lane,
+                                                 double &nz, double &nz64) {
+    const uint64_t tree_key = mix64(mix64(seed) + (uint64_t)t * 0xD1342543DE82EF95ULL + (uint64_t)n_search * 0x9E3779B97F4A7C15ULL);
+    const bool ex = (mask >> lane) & 1ULL;
+    const double lg = ex ? log_gamma_draw(alpha, tree_key + (uint64_t)(lane + 1) * 0xA0761D6478BD642FULL) : -(double)INFINITY;
+    const double lg64 = pass ? log_gamma_draw(alpha, tree_key + 65ULL * 0xA0761D6478BD642FULL) : -(double)INFINITY;   // wave-uniform
+    const double m = fmax(wave_max_f64(lg), lg64);
+    const double e = ex ? exp(lg - m) : 0.0, e64 = pass ? exp(lg64 - m) : 0.0;
+    const double s = wave_sum_f64(e) + e64;
+    nz = e / s;
+    nz64 = e64 / s;
 }
 
 // ---- root set-up (play_game main.py:75-83, run_mcts :100) ----------------------------------------
@@ -238,8 +298,17 @@ __global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, con
     const uint64_t mask = legal[t];
     const int64_t tbase = (int64_t)t * P.max_nodes;
     const bool pass = pass_ok ? pass_ok[t] != 0 : mask == 0;  // reversi.py:125-126: pass only when nothing else is legal
-    write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, pass, noise ? noise + (int64_t)t * MZ_ACTIONS : nullptr,
-                          cfg.noise_frac, lane);
+    const int32_t n_search = P.meta[t].pad[0];   // searches this tree slot has started (mz_pool_init zeroes it)
+    double nz = 0.0, nz64 = 0.0;
+    bool with_noise = noise != nullptr;
+    if (noise) {
+        nz = noise[(int64_t)t * MZ_ACTIONS + lane];
+        nz64 = noise[(int64_t)t * MZ_ACTIONS + 64];
+    } else if (cfg.device_noise && (mask != 0 || pass)) {
+        with_noise = true;
+        device_dirichlet(cfg.noise_alpha, cfg.noise_seed, t, (uint32_t)n_search, mask, pass, lane, nz, nz64);
+    }
+    const double mass = write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, pass, with_noise, nz, nz64, cfg.noise_frac, lane);
     const int eb = P.hidden_elem_bytes;
     copy_hidden(P.hidden + tbase * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
     if (lane == 0) {
@@ -253,10 +322,11 @@ __global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, con
         m.mm_flags = 0;
         m.path_len = 0;
         m.leaf_player = 0;
-        m.error = 0;
+        m.error = bad_policy_mass(mass) ? MZ_TREE_ERR_POLICY_MASS : 0;
         m.leaf_parent = 0;
         m.leaf_action = 0;
-        m.pad[0] = m.pad[1] = 0;
+        m.pad[0] = n_search + 1;
+        m.pad[1] = 0;
         P.meta[t] = m;
     }
 }
@@ -316,7 +386,8 @@ __device__ __forceinline__ int tree_expand(const Pool &P, const float *policy, c
         return -1;
     }
     const int64_t tbase = (int64_t)t * P.max_nodes;
-    write_children<true>(P, tbase + new_id, policy + (int64_t)t * MZ_ACTIONS, ~0ULL, true, nullptr, 0.0, lane);
+    const double mass = write_children<true>(P, tbase + new_id, policy + (int64_t)t * MZ_ACTIONS, ~0ULL, true, false, 0.0, 0.0, 0.0, lane);
+    if (lane == 0 && bad_policy_mass(mass)) meta->error |= MZ_TREE_ERR_POLICY_MASS;
     const int eb = P.hidden_elem_bytes;
     copy_hidden(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
     if (lane == 0) {  // link the leaf to its node: parent's child record gets the expanded id
@@ -435,6 +506,7 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
     ChildRec r = root_recs[lane], r64 = root_recs[64];
 
     const bool ok = new_id < P.max_nodes && depth >= 1;   // tree_expand's guard
+    bool bad_mass = false;
     double prior = 0.0, prior64 = 0.0;
     uint32_t b_nc = 0;     // backup lane k: the new (nc, w) of search_path[k]'s record
     float b_w = 0.0f;
@@ -444,6 +516,7 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
 #pragma unroll
         for (int i = 0; i < 64; ++i) sum += (double)lane_f32(pol, i);
         sum += (double)pol64;
+        bad_mass = bad_policy_mass(sum);
         prior = (double)pol / sum;
         prior64 = (double)pol64 / sum;
         ChildRec *nrecs = P.stats + (tbase + new_id) * MZ_ACTIONS;
@@ -533,6 +606,7 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
             meta->mm_min = mm.lo.d;
             meta->mm_max = mm.hi.d;
             meta->mm_flags = mm_flags;
+            if (bad_mass) meta->error |= MZ_TREE_ERR_POLICY_MASS;
         } else {
             meta->error |= 1;
         }

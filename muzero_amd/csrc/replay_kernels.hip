@@ -62,9 +62,28 @@ __global__ void __launch_bounds__(64) k_replay_sample(mz_replay rb, const int32_
     const int T = rb.max_moves;
     const int64_t slot = slot_in[b];
     const int pos = pos_in[b];
-    if (slot < 0 || slot >= rb.window) return;          // caller bug: leave the sample's rows untouched rather than read out of bounds
-    const int len = rb.length[slot];
-    if (pos < 0 || pos + K > len || len > T) return;    // utilities.py:104 draws pos in [0, len - K]
+    // utilities.py:104 draws pos in [0, len - K].  Anything else is a caller bug: never read out of bounds, never leave the
+    // sample's rows uninitialised (the caller's buffers may come from an allocator that does not clear) -- zeros, and a count
+    const int len = (slot < 0 || slot >= rb.window) ? -1 : rb.length[slot];
+    if (len < 0 || pos < 0 || pos + K > len || len > T) {
+        float *img = image + (int64_t)b * 576;
+        for (int i = lane; i < 576; i += 64) img[i] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float *dst = act + ((int64_t)k * batch + b) * 128;
+            dst[lane] = 0.0f;
+            dst[64 + lane] = 0.0f;
+        }
+        for (int k = 0; k <= K; ++k) {
+            float *dst = tpolicy + ((int64_t)k * batch + b) * MZ_ACTIONS;
+            dst[lane] = 0.0f;
+            if (lane == 0) {
+                dst[64] = 0.0f;
+                tvalue[(int64_t)k * batch + b] = 0.0f;
+            }
+        }
+        if (lane == 0 && rb.refused) atomicAdd(rb.refused, 1);
+        return;
+    }
     // Game.make_image(pos) reversi.py:301-312: plane p, cell = lane
     const uint64_t *hw = rb.white + slot * (T + 1), *hb = rb.black + slot * (T + 1);
     float *img = image + (int64_t)b * 576;

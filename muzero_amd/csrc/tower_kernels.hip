@@ -849,6 +849,8 @@ static int launch_tower(const char *who, const mz_tower_weights *w, const mz_hea
     if (hw) {
         MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_w && hw->p1_b && hw->p2_w && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,
                    "%s: null head pointer", who);
+        // the two Linear matrices are fetched as 16-byte MFMA fragments (heads_prefetch)
+        MZ_REQUIRE((((uintptr_t)hw->p1_w | (uintptr_t)hw->p2_w) & 15) == 0, "%s: heads p1_w / p2_w must be 16-byte aligned", who);
         hd = Heads{hw->pc_w, hw->pc_b, (const uint16_t *)hw->p1_w, hw->p1_b, (const uint16_t *)hw->p2_w, hw->p2_b, hw->vc_w, hw->vc_b, hw->v1_w, hw->v1_b, value, policy};
     }
     const int64_t n_tiles = (n + TILE_BOARDS - 1) / TILE_BOARDS;

@@ -25,7 +25,8 @@ def search_cfg(cfg=None):
                        noise_frac=float(c.root_exploration_fraction), bound_lo=float(kb[0]) if kb else 0.0,
                        bound_hi=float(kb[1]) if kb else 0.0, bounds_none=int(kb is None),
                        tie_lowest=int(bool(getattr(c, "tie_break_lowest", False))),
-                       negamax=int(bool(getattr(c, "negamax_value", False))), reserved=0)
+                       negamax=int(bool(getattr(c, "negamax_value", False))), device_noise=0,
+                       noise_alpha=float(getattr(c, "root_dirichlet_alpha", 0.03)), noise_seed=1261)
 
 
 class BatchedMCTS:
@@ -58,12 +59,17 @@ class BatchedMCTS:
     def _args(self):
         return L.dptr(self.pool), C.byref(self.layout), C.byref(self.cfg)
 
-    def root_init(self, to_play, legal, policy, hidden, noise=None, pass_ok=None):
+    def root_init(self, to_play, legal, policy, hidden, noise=None, pass_ok=None, device_noise_seed=None):
         """play_game main.py:75-83: root expansion over legal actions + exploration noise.
-        to_play int8 (n,), legal int64 (n,), policy f32 (n,65), hidden (n,8,8,8), noise f64 (n,65) by action."""
+        to_play int8 (n,), legal int64 (n,), policy f32 (n,65), hidden (n,8,8,8), noise f64 (n,65) by action.
+        device_noise_seed (with noise=None): draw the Dirichlet noise on the device (mz_search_cfg.device_noise)."""
         self._check(policy, hidden)
-        L.call("mz_mcts_root_init", *self._args(), L.dptr(to_play), L.dptr(legal), L.dptr(pass_ok), L.dptr(policy), L.dptr(noise),
-               L.dptr(hidden), self.n, L.current_stream())
+        cfg = self.cfg
+        if device_noise_seed is not None and noise is None:
+            cfg = L.SearchCfg.from_buffer_copy(self.cfg)
+            cfg.device_noise, cfg.noise_seed = 1, int(device_noise_seed) & (2 ** 64 - 1)
+        L.call("mz_mcts_root_init", L.dptr(self.pool), C.byref(self.layout), C.byref(cfg), L.dptr(to_play), L.dptr(legal), L.dptr(pass_ok),
+               L.dptr(policy), L.dptr(noise), L.dptr(hidden), self.n, L.current_stream())
         self.sims_done = 0
 
     def select(self):

@@ -37,8 +37,9 @@ class ReplayBuffer:
         self.policy = torch.zeros((W, T, 65), dtype=torch.float32, device=d)
         self.root_values = torch.zeros((W, T), dtype=torch.float32, device=d)
         self.length = torch.zeros(W, dtype=torch.int32, device=d)
+        self.refused = torch.zeros(1, dtype=torch.int32, device=d)   # samples mz_replay_sample_batch refused (device counter)
         self._rb = L.Replay(self.white.data_ptr(), self.black.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(),
-                            self.policy.data_ptr(), self.root_values.data_ptr(), self.length.data_ptr(), W, T)
+                            self.policy.data_ptr(), self.root_values.data_ptr(), self.length.data_ptr(), W, T, self.refused.data_ptr())
         self.buffer_size = 0   # utilities.py:52
         self.counter = 0       # utilities.py:54
         self._head = 0         # slot of buffer[0] (the oldest game)
@@ -158,6 +159,10 @@ class ReplayBuffer:
         L.call("mz_replay_sample_batch", L.C.byref(self._rb), L.dptr(sp[0]), L.dptr(sp[1]), B, K, L.dptr(image), L.dptr(actions),
                L.dptr(tv), L.dptr(tp), L.current_stream())
         return image, actions, tv, tp
+
+    def refused_samples(self):
+        """samples the device refused since construction (a host/device length mismatch; synchronises)"""
+        return int(self.refused.item())
 
     def count(self):  # utilities.py:106-109
         temp = self.counter

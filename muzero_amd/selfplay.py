@@ -87,7 +87,11 @@ class SelfPlayEngine:
         self.graph_steps = graph_steps
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
+        self.seed = int(seed)
         self._graph = None
+        self._search_graphs = {}   # whole-search hipGraphs by noise mode ("device" / "given" / "none")
+        self._g_noise = None
+        self._g_ptrs = None
         self._out = None
         self._image = torch.zeros((self.n, 9, 8, 8), dtype=self.dtype, device=self.device)
         self.sims_run = 0
@@ -144,8 +148,65 @@ class SelfPlayEngine:
             self._cap = [self._sim_step() for _ in range(self._graph_steps)]
         self._graph = g
 
-    def search(self, image, noise="auto"):
-        """root set-up + S simulations for all games. Returns (visits (n,65) i32, root_value (n,) f32)."""
+    # ---- the WHOLE search as one hipGraph (HIP inference path): initial inference, root expansion with the Dirichlet noise drawn
+    # inside k_root_init, first descent, S - 1 x [inference + fused tree kernel], last inference, expansion + backup, root
+    # statistics -- 2 S + 5 kernel nodes and nothing else on the stream
+    def _whole_graph_ok(self):
+        return self.use_graph and self.S > 1 and self._net_out() is not None and os.environ.get("MZ_STEP_GRAPH") != "1"
+
+    def _search_body(self, mode):
+        out = self._net_out()
+        v0, p0, h0 = self.net.initial(self._image, out=out)
+        h0 = h0.reshape(self.n, 8, 8, 8)
+        env = self.env
+        if mode == "device":
+            self.mcts.root_init(env.to_play, env.legal, p0, h0, None, device_noise_seed=self.seed)
+        else:
+            self.mcts.root_init(env.to_play, env.legal, p0, h0, self._g_noise if mode == "given" else None)
+        self.mcts.select()
+        for _ in range(self.S - 1):
+            self._sim_step()
+        v, p, h = self._recurrent()
+        L.call("mz_mcts_expand_backup", *self.mcts._args(), L.dptr(v), L.dptr(p), L.dptr(h), self.n, L.current_stream())
+        return self.mcts.root_stats()
+
+    def _search_graph(self, image, noise, mode, copy):
+        env = self.env
+        ptrs = (env.legal.data_ptr(), env.to_play.data_ptr())
+        if self._g_ptrs != ptrs:          # the roots live in other tensors than the captured ones: capture again
+            self._search_graphs.clear()
+            self._g_ptrs = ptrs
+        if image.data_ptr() != self._image.data_ptr():
+            self._image.copy_(image)
+        if mode == "given":
+            if self._g_noise is None:
+                self._g_noise = torch.empty((self.n, 65), dtype=torch.float64, device=self.device)
+            self._g_noise.copy_(noise)
+        ent = self._search_graphs.get(mode)
+        if ent is None:
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):          # warm-up outside the capture (allocator, lazy initialisation)
+                self._search_body(mode)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = self._search_body(mode)
+            ent = self._search_graphs[mode] = (g, res)
+        ent[0].replay()
+        self.mcts.sims_done = self.S
+        self.sims_run += self.S * self.n
+        visits, root_value = ent[1]
+        return (visits.clone(), root_value.clone()) if copy else (visits, root_value)
+
+    def search(self, image, noise="auto", copy=True):
+        """root set-up + S simulations for all games. Returns (visits (n,65) i32, root_value (n,) f32).
+        noise: (n,65) f64 by action, None (no exploration noise), or "auto" = drawn by the engine (on the device inside the
+        root expansion when the search runs as one hipGraph, else from the engine's torch generator).
+        copy=False (hipGraph path): the returned tensors are the graph's own output buffers, overwritten by the next search."""
+        if self._whole_graph_ok():
+            return self._search_graph(image, noise, "device" if isinstance(noise, str) else ("none" if noise is None else "given"), copy)
         out = self._net_out()
         v0, p0, h0 = self.net.initial(image) if out is None else self.net.initial(image, out=out)
         legal, to_play = self.env.legal, self.env.to_play
@@ -187,7 +248,7 @@ class SelfPlayEngine:
         rec.hist_black[0].copy_(env.black)
         for t in range(T):
             make_image(rec.hist_white, rec.hist_black, t, self.n, self.dtype, out=self._image)
-            visits, root_value = self.search(self._image, noise[t].contiguous() if noise is not None else "auto")
+            visits, root_value = self.search(self._image, noise[t].contiguous() if noise is not None else "auto", copy=False)
             ut = u[t].contiguous() if u is not None else torch.rand(self.n, dtype=torch.float64, device=self.device,
                                                                      generator=self.gen)
             action = select_action(visits, t, ut)  # len(action_history) == t for every game

@@ -72,9 +72,13 @@ def gather_game_records(rec, group=None):
     n_max = max(counts)
     out = [dict() for _ in range(world)]
     for k, t in fields.items():
-        if n_local < n_max:
-            pad = torch.zeros((t.shape[0], n_max) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+        if n_local < n_max:   # short rank: one cached pad buffer per field, its tail zeroed once (the head is overwritten every time)
+            pkey = ("pad", k, t.shape[0], n_max, tuple(t.shape[2:]), t.dtype, t.device)
+            pad = _GATHER_BUFFERS.get(pkey)
+            if pad is None:
+                pad = _GATHER_BUFFERS[pkey] = torch.zeros((t.shape[0], n_max) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
             pad[:, :n_local] = t
+            pad[:, n_local:] = 0   # (a rank's shard size never changes in a run; cheap insurance if it does)
             t = pad
         t = t.contiguous()
         key = (k, tuple(t.shape), t.dtype, t.device, world)

@@ -308,6 +308,23 @@ def test_policy_sum_exact_and_rounding_cases():
         L.call("mz_mcts_node_scores", L.dptr(m.pool), L.C.byref(m.layout), L.C.byref(m.cfg), L.dptr(nid), L.dptr(act), L.dptr(score),
                L.dptr(kind), n, L.current_stream())
         score = score.cpu().numpy()
+        # where the reference would raise ZeroDivisionError (main.py:171-175: policy mass exactly 0.0 over the expanded actions),
+        # or the mass is not finite, the tree's error word carries MZ_TREE_ERR_POLICY_MASS (4) -- and only there
+        err = m.meta()[:, MC.META_ERROR].cpu().numpy()
+        seen_flag = 0
+        for t in range(n):
+            legal_t = int(e.legal[t])
+            idx = [a for a in range(64) if (legal_t >> a) & 1] or [64]
+            mass0 = 0.0
+            for a in idx:
+                mass0 += float(p0[t][a])          # Python's ordered double sum, as expand_node's
+            mass1 = 0.0
+            for a in range(65):
+                mass1 += float(p1[t][a])
+            want_flag = any(m_ == 0.0 or not np.isfinite(m_) for m_ in (mass0, mass1))
+            assert bool(err[t] & 4) == want_flag, (fused, t, mass0, mass1, int(err[t]))
+            seen_flag += want_flag
+        assert seen_flag > 0
         for t in range(n):
             o = O.Tree(4, known_bounds=None)
             legal = int(e.legal[t])

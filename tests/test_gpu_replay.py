@@ -166,3 +166,36 @@ def test_narrow_visit_counts_and_strided_views(golden_dir, dt):
         bad = step_major(G, [0])
         bad["visits"] = bad["visits"].float()
         rb.save_games(bad, lengths=[60])
+
+
+def test_refused_samples_are_zero_filled_and_counted():
+    """a (slot, position) pair outside its game reaching the kernel (a direct C caller, or a host/device length mismatch): the
+    sample's rows come back as zeros, never as whatever the output buffers held, and rb->refused counts it"""
+    from muzero_amd import _lib as L
+    from muzero_amd.replay import ReplayBuffer
+    rng = np.random.default_rng(3)
+    n, K = 8, 3
+    G = dict(hist_white=rng.integers(0, 2 ** 63, (n, 61), dtype=np.int64).view(np.uint64),
+             hist_black=rng.integers(0, 2 ** 63, (n, 61), dtype=np.int64).view(np.uint64),
+             actions=rng.integers(0, 65, (n, 60)).astype(np.uint8), rewards=rng.integers(-1, 2, (n, 60)).astype(np.int8),
+             visits=rng.integers(1, 40, (n, 60, 65)).astype(np.int32), root_values=rng.random((n, 60)).astype(np.float32))
+    rb = ReplayBuffer(window_size=n, batch_size=4)
+    rb.save_games(step_major(G, list(range(n))), lengths=[20] * n)
+    slot = torch.tensor([0, n, -1, 1, 2, 3], dtype=torch.int32, device="cuda")        # 1, 2: slot outside the window
+    pos = torch.tensor([5, 0, 0, 18, -1, 17], dtype=torch.int32, device="cuda")       # 3: pos + K > length; 4: pos < 0; 0 and 5 fine
+    B = 6
+    image = torch.full((B, 9, 8, 8), 7.0, device="cuda")
+    acts = torch.full((K, B, 2, 8, 8), 7.0, device="cuda")
+    tv = torch.full((K + 1, B), 7.0, device="cuda")
+    tp = torch.full((K + 1, B, 65), 7.0, device="cuda")
+    L.call("mz_replay_sample_batch", L.C.byref(rb._rb), L.dptr(slot), L.dptr(pos), B, K, L.dptr(image), L.dptr(acts), L.dptr(tv), L.dptr(tp),
+           L.current_stream())
+    assert rb.refused_samples() == 4
+    for b in (1, 2, 3, 4):
+        assert float(image[b].abs().sum()) == 0 and float(acts[:, b].abs().sum()) == 0
+        assert float(tv[:, b].abs().sum()) == 0 and float(tp[:, b].abs().sum()) == 0
+    ref = rb.sample_batch(K, [0, 3], [5, 17])
+    for got, want, sel in ((image, ref[0], None), (acts, ref[1], 1), (tv, ref[2], 1), (tp, ref[3], 1)):
+        g = got[[0, 5]] if sel is None else got[:, [0, 5]]
+        assert torch.equal(g, want)
+    assert not bool((image == 7.0).any() | (acts == 7.0).any() | (tv == 7.0).any() | (tp == 7.0).any())

@@ -94,5 +94,5 @@ def test_bf16_serving_vs_fp32_inference_at_search_level():
     print("bf16 vs fp32 search:", m, "root value |diff| mean %.3g max %.3g" % (float(dv.mean()), float(dv.max())))
     # measured (1024 roots, 50 simulations): top-1 1.000, identical visit vectors 0.985, total variation 2.9e-4, root value
     # |diff| mean 2.9e-5 / max 6.5e-4
-    assert m["top1_agreement"] >= 0.98 and m["identical_visit_vectors"] >= 0.90 and m["mean_total_variation"] <= 5e-3
+    assert m["top1_agreement"] >= 0.98 and m["identical_visit_vectors"] >= 0.97 and m["mean_total_variation"] <= 5e-3
     assert float(dv.mean()) <= 5e-4

@@ -132,3 +132,110 @@ def test_real_network_search_is_sane(dtype):
     assert bool((rv.abs() <= 1).all())
     assert int(eng.mcts.meta()[:, MC.META_ERROR].max()) == 0
     assert int(eng.mcts.meta()[:, MC.META_N_NODES].min()) == 13
+
+
+def test_device_dirichlet_noise_has_the_reference_law():
+    """mz_search_cfg.device_noise: np.random.dirichlet([alpha] * n_children) (main.py:192-193) drawn inside k_root_init.
+    With root_exploration_fraction = 1 the root priors ARE the noise: on the legal actions only, summing to 1, with the
+    moments and the peakedness of numpy's Dirichlet(0.03); a new search draws anew, the same seed and count reproduce."""
+    from muzero_amd import mcts as MC
+
+    class Cfg:
+        pass
+
+    from muzero_amd import config
+    for k in dir(config):
+        if not k.startswith("_"):
+            setattr(Cfg, k, getattr(config, k))
+    Cfg.root_exploration_fraction = 1.0
+    n = 16384
+    rng = np.random.default_rng(5)
+    e, _, _ = _random_roots(n, rng)
+    legal = torch.from_numpy(e.legal.view(np.int64)).cuda()
+    to_play = torch.from_numpy(e.to_play).cuda()
+    policy = torch.full((n, 65), 1.0 / 65, device="cuda")
+    hidden = torch.zeros((n, 8, 8, 8), device="cuda")
+
+    def draw(m, seed):
+        m.root_init(to_play, legal, policy, hidden, None, device_noise_seed=seed)
+        return m.root_stats(with_debug=True)[3].cpu().numpy()
+
+    m = MC.BatchedMCTS(n, 2, torch.float32, cfg=Cfg)
+    a = draw(m, 77)
+    b = draw(m, 77)                       # the slot's search count moved on: other draws
+    m2 = MC.BatchedMCTS(n, 2, torch.float32, cfg=Cfg)
+    a2 = draw(m2, 77)                     # same seed, same count: the same draws
+    c = draw(MC.BatchedMCTS(n, 2, torch.float32, cfg=Cfg), 78)
+    assert (a == a2).all() and (a != b).any() and (a != c).any()
+    bits = ((e.legal[:, None] >> np.arange(64, dtype=np.uint64)) & 1).astype(bool)
+    mask = np.concatenate([bits, (e.legal == 0)[:, None]], 1)
+    assert (a[~mask] == 0).all() and np.abs(a.sum(1) - 1).max() < 1e-12 and (a >= 0).all()
+    # law: compare with numpy's Dirichlet per number of children k (every k with enough roots)
+    kk = mask.sum(1)
+    checked = 0
+    for k in np.unique(kk):
+        rows = np.nonzero(kk == k)[0]
+        if len(rows) < 600 or k < 2:
+            continue
+        x = np.concatenate([a[rows][mask[rows]].reshape(len(rows), k), b[rows][mask[rows]].reshape(len(rows), k)])
+        ref = np.random.default_rng(1).dirichlet([0.03] * k, 200000)
+        a0 = 0.03 * k
+        var = 0.03 * (a0 - 0.03) / (a0 * a0 * (a0 + 1))
+        se = np.sqrt(var / x.size)
+        assert abs(x.mean() - 1.0 / k) < 1e-9                     # rows sum to 1
+        assert abs(x[:, 0].mean() - 1.0 / k) < 5 * np.sqrt(var / len(x)), k
+        assert abs(x.var() - var) < 0.02, (k, x.var(), var)
+        for thr in (0.5, 0.9, 0.999):
+            p_got, p_ref = (x.max(1) > thr).mean(), (ref.max(1) > thr).mean()
+            assert abs(p_got - p_ref) < 5 * np.sqrt(p_ref * (1 - p_ref) / len(x)) + 0.01, (k, thr, p_got, p_ref)
+        checked += 1
+        del se
+    assert checked >= 3
+    one = np.nonzero(kk == 1)[0]          # a single child (a forced move or the pass): the sample is exactly [1]
+    if len(one):
+        assert (a[one][mask[one]] == 1.0).all()
+
+
+def _random_roots(n, rng):
+    """positions after 0..59 random moves (oracle playouts), as host arrays"""
+    from oracle import mz_oracle as O
+    steps = rng.integers(0, 60, n)
+    out = O.EnvBatch(n)
+    for s in np.unique(steps):
+        idx = np.nonzero(steps == s)[0]
+        e = O.random_playout(4242, int(idx[0]), len(idx), int(s))[0]
+        for f in ("black", "white", "to_play", "steps", "done", "legal"):
+            getattr(out, f)[idx] = getattr(e, f)
+    return out, None, None
+
+
+def test_whole_search_graph_equals_the_kernel_by_kernel_search():
+    """the search as ONE hipGraph (initial inference, root expansion, S x [inference + tree kernel], root statistics) against
+    the same launches issued one by one: identical visits and root values with caller-supplied noise and with none; with the
+    engine's own noise (drawn inside the root expansion) every tree completes S simulations and consecutive searches differ"""
+    from muzero_amd import mcts as MC
+    from muzero_amd.env import make_image
+    from muzero_amd.network import InferenceEngine, Network
+    from muzero_amd.selfplay import SelfPlayEngine
+    from bench import make_roots
+    torch.manual_seed(1261)
+    n, S = 256, 24
+    served = InferenceEngine(Network(), n, torch.bfloat16)
+    r, hw, hb, idx = make_roots(n, 1261, 0, torch.device("cuda"))
+    image = make_image(hw, hb, idx, n, torch.bfloat16)
+    eager = SelfPlayEngine(n, served, num_simulations=S, use_graph=False, seed=3)
+    graph = SelfPlayEngine(n, served, num_simulations=S, use_graph=True, seed=3)
+    eager.env = graph.env = r
+    noise = eager.dirichlet_noise(r.legal)
+    for nz in (noise, None, noise):
+        want = eager.search(image, nz)
+        got = graph.search(image, nz)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1].view(torch.int32), want[1].view(torch.int32))
+    assert set(graph._search_graphs) == {"given", "none"}
+    v1, _ = graph.search(image)            # "auto": device noise
+    p1 = graph.mcts.root_stats(with_debug=True)[3].clone()
+    v2, _ = graph.search(image)
+    p2 = graph.mcts.root_stats(with_debug=True)[3]
+    assert int(v1.clamp(min=0).sum(1).min()) == S and int(v2.clamp(min=0).sum(1).max()) == S
+    assert bool((p1 != p2).any()) and int(graph.mcts.meta()[:, MC.META_ERROR].max()) == 0
+    assert abs(float(p1.sum(1).mean()) - 1.0) < 1e-9

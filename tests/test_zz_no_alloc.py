@@ -51,6 +51,33 @@ def test_noalloc_equals_workspace_search_twice_second_smaller():
         # the Python wrapper of the same entry point
         v3, r3 = FusedSearch(served, n, S, noalloc=True)(image, e.to_play, e.legal, noise)
         assert torch.equal(v3, want_v) and torch.equal(r3.view(torch.int32), want_r.view(torch.int32))
+        # what the header promises beyond the results: after the warm-up calls above, a call (a) takes no device memory --
+        # the free bytes the driver reports do not move around it -- and (b) can be recorded into a hipGraph (a hipMalloc, a
+        # synchronisation or a synchronous copy inside it would fail the capture) and replayed with the same results
+        out_v = torch.empty((n, 65), dtype=torch.int32, device="cuda")
+        out_r = torch.empty(n, dtype=torch.float32, device="cuda")
+
+        def call_into():
+            L.call("mz_search_noalloc", *fs._weights(), C.byref(fs.cfg), L.dptr(image), L.dptr(e.to_play), L.dptr(e.legal), L.dptr(noise), S, n,
+                   L.dptr(out_v), L.dptr(out_r), L.current_stream())
+
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        call_into()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, "mz_search_noalloc changed the device's free memory"
+        assert torch.equal(out_v, want_v)
+        out_v.fill_(-7)
+        out_r.fill_(0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            call_into()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            out_v.fill_(-7)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out_v, want_v) and torch.equal(out_r.view(torch.int32), want_r.view(torch.int32))
 
 
 def test_noalloc_rejects_sizes_beyond_the_static_array():
