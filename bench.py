@@ -414,13 +414,17 @@ def main():
         # nothing but k_backup_select between the two events on the launch stream)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tot_ms, launches = 0.0, 0
+        routed = eng._whole_graph_ok()
         for rep in range(5):
             eng.mcts.root_init(roots.to_play, roots.legal, p0, h0, noise)
             eng.mcts.select()
             torch.cuda.synchronize()
             start.record()
             for s in range(S - 1):
-                eng.mcts.backup_select(*rec[s])
+                if routed:   # the form the timed search runs: no hidden-state traffic in the tree kernel
+                    eng.mcts.backup_select_routed(rec[s][0], rec[s][1])
+                else:
+                    eng.mcts.backup_select(*rec[s])
             end.record()
             end.synchronize()
             tot_ms += start.elapsed_time(end)
@@ -429,18 +433,22 @@ def main():
         d = depth_sum / (S - 1)
         eb = 2 if dtype != torch.float32 else 4
         # algorithmic bytes per simulation: descent d x 65 x 16 B; expansion 260+4 B in, 65 x 16 B out;
-        # backup (d+1) x 16 B r/w; path/leaf records 16 B; hidden state: copy-in 2 x 512 x eb, gather 512 x eb in + 640 x eb out
+        # backup (d+1) x 16 B r/w; path/leaf records 16 B; then what the kernel moves for the network input: routed = two action
+        # planes + two slot words (the hidden states stay in the pool); rows = hidden copy-in 2 x 512 x eb, gather 512 x eb in + 640 x eb out
         tree_bytes = 1040.0 * d + 1040 + 264 + 16.0 * (d + 1) + 16
-        hid_bytes = (2 * 512 + 512 + 640) * eb
+        hid_bytes = (128 * eb + 8) if routed else (2 * 512 + 512 + 640) * eb
+        survey_bytes = 796.0 * d + 1076     # 12-byte child records, hidden traffic accounted to the inference step
         us = tot_ms / launches * 1e3
         gbps = n * (tree_bytes + hid_bytes) / (us * 1e-6) / 1e9
         out["roofline_tree"] = {"kernel": "k_backup_select", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic("k_backup_select"), "traffic_source": pmc_traffic_src("k_backup_select")[1], "us_per_launch": us,
-                                "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes,
+                                "mean_depth": d, "bytes_per_sim_tree": tree_bytes, "bytes_per_sim_hidden": hid_bytes, "routed": bool(routed),
+                                "bytes_per_sim_survey": survey_bytes, "frac_survey_bytes": n * survey_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                 "trees_per_launch": n, "algorithmic_bytes_per_launch": n * (tree_bytes + hid_bytes),
                                 "share_of_step": us * 1e-3 / (dt / args.steps / S * 1e3),
-                                "note": "HBM fraction as SURVEY 8(d) defines it; under load the kernel is bound by the latency of ~25 scattered 1 KB requests per "
-                                        "tree (waves wait 60 % of their cycles, VALU active 15 %), not by bandwidth: profiles/r02/tree_experiment_latency.txt",
+                                "note": "frac = this build's byte count (16-byte child records with float64 priors) over time; frac_survey_bytes = SURVEY "
+                                        "8(d)'s 796 d + 1076.  The kernel is a chain of dependent scattered 1 KB reads per tree (latency, not bandwidth): "
+                                        "profiles/r02/tree_experiment_latency.txt",
                                 "valu_static": {k: (kernel_isa("k_backup_select") or {}).get(k) for k in
                                                 ("valu_instructions", "fp64_valu_instructions", "salu_instructions", "vmem_instructions", "has_loop")}}
         # ---- the dominant kernel of the timed region: the inference launch (k_tower: conv tower + heads, ~97 % of a

@@ -199,7 +199,8 @@ int mz_mcts_select(void *pool, const mz_pool_layout *layout, const mz_search_cfg
                    int32_t n_trees, void *stream);
 
 /* expand_node over all 65 actions (main.py:123,165-175) + backpropagate (:180-186) along the path
- * stored by mz_mcts_select.  value: (n) f32, policy: (n,65) f32, hidden: (n,512) pool dtype. */
+ * stored by mz_mcts_select.  value: (n) f32, policy: (n,65) f32, hidden: (n,512) pool dtype, or NULL when the new
+ * nodes' hidden states are in their pool slots already (routed inference, below). */
 int mz_mcts_expand_backup(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
                           const float *value, const float *policy, const void *hidden, int32_t n_trees,
                           void *stream);
@@ -209,6 +210,22 @@ int mz_mcts_expand_backup(void *pool, const mz_pool_layout *layout, const mz_sea
 int mz_mcts_backup_select(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg,
                           const float *value, const float *policy, const void *hidden, void *net_in,
                           int32_t n_trees, void *stream);
+
+/* The ROUTED form of the same calls: no hidden state is copied by the tree kernels.  run_mcts keeps every node's
+ * hidden_state in the node (main.py:114-123: parent.hidden_state in, node.hidden_state out); here the inference launch
+ * itself reads the parent's state from its pool slot and writes the new node's state into ITS slot
+ * (mz_inference_forward_routed), and a descent only says which slots: slot = tree * max_nodes + node.  The new node's id is
+ * known before the expansion (ids are handed out in order).  Only the two Action.encode planes travel through a row.
+ * With routing, mz_mcts_root_init / mz_mcts_expand_backup take hidden = NULL ("already in place"). */
+typedef struct mz_leaf_route {
+    int32_t *src_slot;  /* [n] out: pool slot of the leaf's parent (the recurrent inference's input planes 0..7) */
+    int32_t *dst_slot;  /* [n] out: pool slot of the node the next expansion creates (the inference's hidden output) */
+    void *act_planes;   /* (n,2,8,8) out, pool hidden dtype: Action(a, child's player).encode() (main.py:110, reversi.py:32-36) */
+} mz_leaf_route;
+int mz_mcts_select_routed(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg, const mz_leaf_route *route,
+                          int32_t n_trees, void *stream);
+int mz_mcts_backup_select_routed(void *pool, const mz_pool_layout *layout, const mz_search_cfg *cfg, const float *value,
+                                 const float *policy, const mz_leaf_route *route, int32_t n_trees, void *stream);
 
 /* the two halves of mz_mcts_expand_backup as separate calls, for callers that keep the reference's
  * call structure: expand_node (main.py:165-175) of the leaf reached by the last mz_mcts_select,
@@ -352,6 +369,17 @@ typedef struct mz_heads_weights {
  * Outputs the tuple the search consumes: value (n) f32, policy (n,65) f32 softmaxed, hidden (n,8,8,8). */
 int mz_inference_forward(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, void *hidden,
                          int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream);
+
+/* The same launch with its hidden states gathered from / scattered into a pool of 512-element rows (the search pool's hidden
+ * region, pool + layout.off_hidden): recurrent_inference(parent.hidden_state, action) -> node.hidden_state (main.py:114-123)
+ * without the two copies around it.
+ *   src_pool, src_slot : input planes 0..7 of board b = row src_slot[b] of src_pool (bf16); x then holds only the
+ *                        remaining cin - 8 planes, (n, cin - 8, 8, 8) bf16.  src_pool NULL: x holds all cin planes.
+ *   dst_pool, dst_slot, dst_stride : board b's hidden output goes to row dst_slot[b] of dst_pool, or, dst_slot NULL, to row
+ *                        b * dst_stride (initial inference into every tree's root slot: dst_stride = max_nodes). */
+int mz_inference_forward_routed(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, const void *src_pool,
+                                const int32_t *src_slot, void *dst_pool, const int32_t *dst_slot, int64_t dst_stride,
+                                int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * One whole search per call: the per-move body of play_game (main.py:75-87) for n_trees games with the

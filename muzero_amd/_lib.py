@@ -44,6 +44,11 @@ class Replay(C.Structure):
                 ("window", C.c_int32), ("max_moves", C.c_int32), ("refused", C.c_void_p)]
 
 
+class LeafRoute(C.Structure):
+    """mz_leaf_route -- where a routed descent names the pool slots of its leaf"""
+    _fields_ = [("src_slot", C.c_void_p), ("dst_slot", C.c_void_p), ("act_planes", C.c_void_p)]
+
+
 class TowerWeights(C.Structure):
     """mz_tower_weights -- device pointers to the prepacked tower weights"""
     _fields_ = [("w_first", C.c_void_p), ("b_first", C.c_void_p), ("w_mid", C.c_void_p), ("b_mid", C.c_void_p),
@@ -90,6 +95,9 @@ SIGNATURES = {
     "mz_bias_act_nhwc": [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
     "mz_tower_forward": [C.POINTER(TowerWeights), _p, _p, _i32, _i64, _p],
     "mz_inference_forward": [C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _p, _p, _i32, _p, _p, _i64, _p],
+    "mz_inference_forward_routed": [C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _p],
+    "mz_mcts_select_routed": [_p, _LP, _CP, C.POINTER(LeafRoute), _i32, _p],
+    "mz_mcts_backup_select_routed": [_p, _LP, _CP, _p, _p, C.POINTER(LeafRoute), _i32, _p],
     "mz_search": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32, _p, _i64,
                   _p, _p, _p],
     "mz_search_noalloc": [C.POINTER(TowerWeights), C.POINTER(TowerWeights), C.POINTER(HeadsWeights), _CP, _p, _p, _p, _p, _i32, _i32,

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, con
     }
     const double mass = write_children<false>(P, tbase, policy + (int64_t)t * MZ_ACTIONS, mask, pass, with_noise, nz, nz64, cfg.noise_frac, lane);
     const int eb = P.hidden_elem_bytes;
-    copy_hidden(P.hidden + tbase * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
+    if (hidden) copy_hidden(P.hidden + tbase * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
     if (lane == 0) {
         mz_tree_meta m;
         m.n_nodes = 1;
@@ -331,8 +331,34 @@ __global__ void __launch_bounds__(64) k_root_init(Pool P, mz_search_cfg cfg, con
     }
 }
 
+// ---- where a descent leaves the network input of its leaf ------------------------------------------------------------------
+//   rows   (net_in != null): one (10,8,8) row per tree = parent hidden (8 planes, copied out of the pool) ++ action planes
+//   routed (net_in == null): nothing is copied.  The inference launch reads the parent's hidden state from the pool slot
+//          src_slot[t] and writes the new node's hidden state straight into the slot dst_slot[t] (mz_inference_forward_routed);
+//          only the two action planes travel through a staging row.  The new node's id is known before it is expanded: ids
+//          are handed out in order, so it is the tree's node count.
+struct LeafOut {
+    char *net_in;
+    int32_t *src_slot, *dst_slot;
+    char *act;   // (n,2,8,8) of the pool's hidden dtype
+};
+__device__ __forceinline__ void write_action_planes(const Pool &P, char *dst, int a, int player, int lane) {
+    // Action(a, child's player).encode() (reversi.py:32-36): rows r and c of the mover's layer, pass = whole layer
+    const int layer = lane >> 5, cell = (2 * lane) & 63, my_layer = player == 1 ? 0 : 1;
+    const bool set = layer == my_layer && ((encode_rows(a) >> (cell >> 3)) & 1u);
+    if (P.hidden_elem_bytes == 4) ((float2 *)dst)[lane] = set ? make_float2(1.0f, 1.0f) : make_float2(0.0f, 0.0f);
+    else ((uint32_t *)dst)[lane] = set ? P.one16x2 : 0u;
+}
+__device__ __forceinline__ void write_route(const Pool &P, const LeafOut &out, int t, int64_t tbase, int node, int next_id, int a, int player, int lane) {
+    if (lane == 0) {
+        out.src_slot[t] = (int32_t)(tbase + node);
+        out.dst_slot[t] = (int32_t)(tbase + (next_id < P.max_nodes ? next_id : P.max_nodes - 1));   // a full pool is flagged; never out of range
+    }
+    write_action_planes(P, out.act + (int64_t)t * (128 * P.hidden_elem_bytes), a, player, lane);
+}
+
 // ---- one simulation's descent (run_mcts main.py:103-118) ------------------------------------------
-__device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &cfg, char *net_in, int t, int lane) {
+__device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &cfg, const LeafOut &out, int t, int lane) {
     mz_tree_meta *meta = &P.meta[t];
     const MinMax mm = load_minmax(meta);
     const int64_t tbase = (int64_t)t * P.max_nodes;
@@ -364,16 +390,15 @@ __device__ __forceinline__ void tree_select(const Pool &P, const mz_search_cfg &
         meta->leaf_parent = node;
         meta->leaf_action = a;
     }
+    if (!out.net_in) {
+        write_route(P, out, t, tbase, node, meta->n_nodes, a, player, lane);
+        return;
+    }
     // network input row: parent hidden (8 planes) ++ Action(a, child's player).encode() (2 planes)
     const int eb = P.hidden_elem_bytes;
-    char *row = net_in + (int64_t)t * (640 * eb);
+    char *row = out.net_in + (int64_t)t * (640 * eb);
     copy_hidden(row, P.hidden + (tbase + node) * (int64_t)(MZ_HIDDEN_ELEMS * eb), eb, lane);
-    const int layer = lane >> 5, cell = (2 * lane) & 63, my_layer = player == 1 ? 0 : 1;
-    const bool set = layer == my_layer && ((encode_rows(a) >> (cell >> 3)) & 1u);
-    if (eb == 4)
-        ((float2 *)(row + 512 * 4))[lane] = set ? make_float2(1.0f, 1.0f) : make_float2(0.0f, 0.0f);
-    else
-        ((uint32_t *)(row + 512 * 2))[lane] = set ? P.one16x2 : 0u;
+    write_action_planes(P, row + 512 * eb, a, player, lane);
 }
 
 // ---- expand the leaf (main.py:123, 165-175) -------------------------------------------------------
@@ -389,7 +414,8 @@ __device__ __forceinline__ int tree_expand(const Pool &P, const float *policy, c
     const double mass = write_children<true>(P, tbase + new_id, policy + (int64_t)t * MZ_ACTIONS, ~0ULL, true, false, 0.0, 0.0, 0.0, lane);
     if (lane == 0 && bad_policy_mass(mass)) meta->error |= MZ_TREE_ERR_POLICY_MASS;
     const int eb = P.hidden_elem_bytes;
-    copy_hidden(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
+    if (hidden)   // (null: the inference launch has written the node's hidden state into its slot already)
+        copy_hidden(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb), hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb), eb, lane);
     if (lane == 0) {  // link the leaf to its node: parent's child record gets the expanded id
         const PathRec pr = P.path[tbase + depth - 1];
         ChildRec *rec = P.stats + (tbase + pr.node) * MZ_ACTIONS + pr.action;
@@ -455,8 +481,8 @@ __device__ __forceinline__ void tree_expand_backup(const Pool &P, const mz_searc
     tree_backup(P, cfg, value[t], t, lane);
 }
 
-__global__ void __launch_bounds__(64) k_select(Pool P, mz_search_cfg cfg, char *net_in) {
-    tree_select(P, cfg, net_in, blockIdx.x, threadIdx.x);
+__global__ void __launch_bounds__(64) k_select(Pool P, mz_search_cfg cfg, LeafOut out) {
+    tree_select(P, cfg, out, blockIdx.x, threadIdx.x);
 }
 __global__ void __launch_bounds__(64) k_expand_backup(Pool P, mz_search_cfg cfg, const float *value, const float *policy,
                                                       const char *hidden) {
@@ -477,14 +503,14 @@ __global__ void __launch_bounds__(64) k_expand_backup(Pool P, mz_search_cfg cfg,
 // Typical step (old depth 1-2, new depth 1-2): 3-4 rounds instead of 8-9.  Paths longer than 62
 // edges (degenerate chains) take the plain three-function route.
 __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg, const float *value, const float *policy,
-                                                      const char *hidden, char *net_in) {
+                                                      const char *hidden, LeafOut out) {
     const int t = blockIdx.x, lane = threadIdx.x;
     mz_tree_meta *meta = &P.meta[t];
     const int depth = meta->path_len;
     if (depth > 62) {
         tree_expand_backup(P, cfg, value, policy, hidden, t, lane);
         __syncthreads();  // the descent re-reads records other lanes of this wave have just written
-        tree_select(P, cfg, net_in, t, lane);
+        tree_select(P, cfg, out, t, lane);
         return;
     }
     const int64_t tbase = (int64_t)t * P.max_nodes;
@@ -499,9 +525,14 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
     const PathRec oldp = lane < P.max_nodes ? P.path[tbase + lane] : PathRec{0, 0, 0};  // old search_path edge `lane`
     const float pol = policy[(int64_t)t * MZ_ACTIONS + lane], pol64 = policy[(int64_t)t * MZ_ACTIONS + 64];
     const float v0 = value[t];
-    const uint4 *hsrc = reinterpret_cast<const uint4 *>(hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb));
-    const uint4 hin0 = hsrc[lane];
-    const uint4 hin1 = n16 > 64 ? hsrc[lane + 64] : make_uint4(0, 0, 0, 0);
+    // the new node's hidden state: copied into the pool from the inference launch's output row -- unless that launch wrote
+    // it into the node's slot itself (hidden == null: the routed form, no hidden-state traffic in this kernel at all)
+    uint4 hin0 = make_uint4(0, 0, 0, 0), hin1 = make_uint4(0, 0, 0, 0);
+    if (hidden) {
+        const uint4 *hsrc = reinterpret_cast<const uint4 *>(hidden + (int64_t)t * (MZ_HIDDEN_ELEMS * eb));
+        hin0 = hsrc[lane];
+        if (n16 > 64) hin1 = hsrc[lane + 64];
+    }
     const ChildRec *root_recs = P.stats + tbase * MZ_ACTIONS;
     ChildRec r = root_recs[lane], r64 = root_recs[64];
 
@@ -522,9 +553,11 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
         ChildRec *nrecs = P.stats + (tbase + new_id) * MZ_ACTIONS;
         nrecs[lane] = ChildRec{0u, 0.0f, prior};
         if (lane == 0) nrecs[64] = ChildRec{0u, 0.0f, prior64};
-        uint4 *hdst = reinterpret_cast<uint4 *>(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb));
-        hdst[lane] = hin0;
-        if (n16 > 64) hdst[lane + 64] = hin1;
+        if (hidden) {
+            uint4 *hdst = reinterpret_cast<uint4 *>(P.hidden + (tbase + new_id) * (int64_t)(MZ_HIDDEN_ELEMS * eb));
+            hdst[lane] = hin0;
+            if (n16 > 64) hdst[lane + 64] = hin1;
+        }
         // ---- backpropagate main.py:180-186: lane k owns search_path[k], k = 0 .. depth ----
         const int prev = __shfl_up(*reinterpret_cast<const int *>(&oldp), 1, 64);   // path[k-1]
         const int pnode = prev & 0xFFFF, pact = (prev >> 16) & 0xFF;
@@ -615,10 +648,14 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
         meta->leaf_parent = node;
         meta->leaf_action = a;
     }
+    if (!out.net_in) {
+        write_route(P, out, t, tbase, node, ok ? new_id + 1 : new_id, a, player, lane);
+        return;
+    }
     // network input row: parent hidden (8 planes) ++ Action(a, child's player).encode() (2 planes)
-    char *row = net_in + (int64_t)t * (640 * eb);
+    char *row = out.net_in + (int64_t)t * (640 * eb);
     uint4 *rdst = reinterpret_cast<uint4 *>(row);
-    if (ok && node == new_id) {
+    if (ok && node == new_id && hidden) {
         rdst[lane] = hin0;
         if (n16 > 64) rdst[lane + 64] = hin1;
     } else {
@@ -626,12 +663,7 @@ __global__ void __launch_bounds__(64) k_backup_select(Pool P, mz_search_cfg cfg,
         rdst[lane] = ps[lane];
         if (n16 > 64) rdst[lane + 64] = ps[lane + 64];
     }
-    const int layer = lane >> 5, cell = (2 * lane) & 63, my_layer = player == 1 ? 0 : 1;
-    const bool set = layer == my_layer && ((encode_rows(a) >> (cell >> 3)) & 1u);
-    if (eb == 4)
-        ((float2 *)(row + 512 * 4))[lane] = set ? make_float2(1.0f, 1.0f) : make_float2(0.0f, 0.0f);
-    else
-        ((uint32_t *)(row + 512 * 2))[lane] = set ? P.one16x2 : 0u;
+    write_action_planes(P, row + 512 * eb, a, player, lane);
 }
 
 // ---- single-call entry points for the reference-shaped Python API (muzero_amd/compat.py) ----------
@@ -843,7 +875,7 @@ extern "C" int mz_mcts_root_init(void *pool, const mz_pool_layout *L, const mz_s
                                  const void *hidden, int32_t n_trees, void *stream) {
     if (int rc = check_pool("mz_mcts_root_init", pool, L, n_trees)) return rc;
     if (n_trees == 0) return MZ_OK;
-    MZ_REQUIRE(cfg && to_play && legal && policy && hidden, "mz_mcts_root_init: null pointer");
+    MZ_REQUIRE(cfg && to_play && legal && policy, "mz_mcts_root_init: null pointer");   // hidden null: already in the roots' pool slots
     hipLaunchKernelGGL(k_root_init, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, to_play, legal, pass_ok,
                        policy, noise, (const char *)hidden);
     MZ_LAUNCH_CHECK("k_root_init");
@@ -855,8 +887,38 @@ extern "C" int mz_mcts_select(void *pool, const mz_pool_layout *L, const mz_sear
     if (int rc = check_pool("mz_mcts_select", pool, L, n_trees)) return rc;
     if (n_trees == 0) return MZ_OK;
     MZ_REQUIRE(cfg && net_in, "mz_mcts_select: null pointer");
-    hipLaunchKernelGGL(k_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, (char *)net_in);
+    hipLaunchKernelGGL(k_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, LeafOut{(char *)net_in, nullptr, nullptr, nullptr});
     MZ_LAUNCH_CHECK("k_select");
+    return MZ_OK;
+}
+
+static int check_route(const char *who, const mz_pool_layout *L, const mz_leaf_route *r) {
+    MZ_REQUIRE(r && r->src_slot && r->dst_slot && r->act_planes, "%s: null pointer in mz_leaf_route", who);
+    MZ_REQUIRE((int64_t)L->n_trees * L->max_nodes < (int64_t)1 << 31, "%s: pool slots do not fit int32", who);
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_select_routed(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const mz_leaf_route *route,
+                                     int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_select_routed", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg, "mz_mcts_select_routed: null pointer");
+    if (int rc = check_route("mz_mcts_select_routed", L, route)) return rc;
+    hipLaunchKernelGGL(k_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg,
+                       LeafOut{nullptr, route->src_slot, route->dst_slot, (char *)route->act_planes});
+    MZ_LAUNCH_CHECK("k_select");
+    return MZ_OK;
+}
+
+extern "C" int mz_mcts_backup_select_routed(void *pool, const mz_pool_layout *L, const mz_search_cfg *cfg, const float *value,
+                                            const float *policy, const mz_leaf_route *route, int32_t n_trees, void *stream) {
+    if (int rc = check_pool("mz_mcts_backup_select_routed", pool, L, n_trees)) return rc;
+    if (n_trees == 0) return MZ_OK;
+    MZ_REQUIRE(cfg && value && policy, "mz_mcts_backup_select_routed: null pointer");
+    if (int rc = check_route("mz_mcts_backup_select_routed", L, route)) return rc;
+    hipLaunchKernelGGL(k_backup_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value, policy,
+                       (const char *)nullptr, LeafOut{nullptr, route->src_slot, route->dst_slot, (char *)route->act_planes});
+    MZ_LAUNCH_CHECK("k_backup_select");
     return MZ_OK;
 }
 
@@ -864,7 +926,7 @@ extern "C" int mz_mcts_expand_backup(void *pool, const mz_pool_layout *L, const 
                                      const float *policy, const void *hidden, int32_t n_trees, void *stream) {
     if (int rc = check_pool("mz_mcts_expand_backup", pool, L, n_trees)) return rc;
     if (n_trees == 0) return MZ_OK;
-    MZ_REQUIRE(cfg && value && policy && hidden, "mz_mcts_expand_backup: null pointer");
+    MZ_REQUIRE(cfg && value && policy, "mz_mcts_expand_backup: null pointer");   // hidden null: already in the new nodes' pool slots
     hipLaunchKernelGGL(k_expand_backup, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value, policy,
                        (const char *)hidden);
     MZ_LAUNCH_CHECK("k_expand_backup");
@@ -877,7 +939,7 @@ extern "C" int mz_mcts_backup_select(void *pool, const mz_pool_layout *L, const 
     if (n_trees == 0) return MZ_OK;
     MZ_REQUIRE(cfg && value && policy && hidden && net_in, "mz_mcts_backup_select: null pointer");
     hipLaunchKernelGGL(k_backup_select, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, make_pool(pool, L), *cfg, value, policy,
-                       (const char *)hidden, (char *)net_in);
+                       (const char *)hidden, LeafOut{(char *)net_in, nullptr, nullptr, nullptr});
     MZ_LAUNCH_CHECK("k_backup_select");
     return MZ_OK;
 }

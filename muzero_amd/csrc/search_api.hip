@@ -49,16 +49,24 @@ int mz_check_search_args(const char *who, const mz_tower_weights *repr, const mz
 int mz_run_search(const mz_tower_weights *repr, const mz_tower_weights *dyn, const mz_heads_weights *heads, const mz_search_cfg *cfg,
                const void *image, const int8_t *to_play, const uint64_t *legal, const double *noise, int32_t S, int32_t n,
                char *ws, const SearchPlan &P, int32_t *visits, float *root_value, void *stream) {
-    void *net_in = ws + P.off_net_in, *hidden = ws + P.off_hidden;
+    // Routed: hidden states never leave the pool.  The inference launch reads the leaf's parent from its slot and writes the
+    // new node's state into its slot; the descents only name the slots (mz_leaf_route, carved out of the net_in staging row
+    // region, of which only the action planes are still used).
     float *value = (float *)(ws + P.off_value), *policy = (float *)(ws + P.off_policy);
-    if (int rc = mz_inference_forward(repr, heads, image, hidden, MZ_BF16, value, policy, n, stream)) return rc;   // network.py:146-153
-    if (int rc = mz_mcts_root_init(ws, &P.L, cfg, to_play, legal, nullptr, policy, noise, hidden, n, stream)) return rc;
+    char *hpool = ws + P.L.off_hidden;
+    const int64_t slot_bytes = up256((int64_t)n * 4);
+    static_assert(2 * 256 + 256 <= 640 * 2, "the route fits the staging row region for any n >= 1");
+    const mz_leaf_route rt{(int32_t *)(ws + P.off_net_in), (int32_t *)(ws + P.off_net_in + slot_bytes), ws + P.off_net_in + 2 * slot_bytes};
+    if (int rc = mz_inference_forward_routed(repr, heads, image, nullptr, nullptr, hpool, nullptr, P.L.max_nodes, MZ_BF16, value, policy, n, stream))
+        return rc;   // network.py:146-153, hidden state -> every tree's root slot
+    if (int rc = mz_mcts_root_init(ws, &P.L, cfg, to_play, legal, nullptr, policy, noise, nullptr, n, stream)) return rc;
     if (S > 0) {
-        if (int rc = mz_mcts_select(ws, &P.L, cfg, net_in, n, stream)) return rc;
+        if (int rc = mz_mcts_select_routed(ws, &P.L, cfg, &rt, n, stream)) return rc;
         for (int s = 0; s < S; ++s) {
-            if (int rc = mz_inference_forward(dyn, heads, net_in, hidden, MZ_BF16, value, policy, n, stream)) return rc;   // network.py:155-163
-            const int rc = s + 1 < S ? mz_mcts_backup_select(ws, &P.L, cfg, value, policy, hidden, net_in, n, stream)
-                                     : mz_mcts_expand_backup(ws, &P.L, cfg, value, policy, hidden, n, stream);
+            if (int rc = mz_inference_forward_routed(dyn, heads, rt.act_planes, hpool, rt.src_slot, hpool, rt.dst_slot, 1, MZ_BF16, value, policy, n, stream))
+                return rc;   // network.py:155-163
+            const int rc = s + 1 < S ? mz_mcts_backup_select_routed(ws, &P.L, cfg, value, policy, &rt, n, stream)
+                                     : mz_mcts_expand_backup(ws, &P.L, cfg, value, policy, nullptr, n, stream);
             if (rc) return rc;
         }
     }

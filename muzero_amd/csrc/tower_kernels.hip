@@ -82,6 +82,15 @@ struct Heads {
     float *value, *policy;       // outputs (n), (n,65); null = heads off
 };
 
+// where the hidden states around the tower live (mz_inference_forward_routed): rows of 512 elements
+struct Route {
+    const uint16_t *src_pool;   // null: x holds all cin planes
+    const int32_t *src_slot;
+    const int32_t *dst_slot;    // null: row = board * dst_stride
+    int64_t dst_stride;         // 1: the plain (n, 512) output
+};
+__device__ __forceinline__ int64_t dst_row(const Route &rt, int64_t b) { return rt.dst_slot ? (int64_t)rt.dst_slot[b] : b * rt.dst_stride; }
+
 __device__ __forceinline__ int act_key(int q) { return (((q >> 3) & 1) << 3) | (q & 7); }
 // MFMA 16x16x32 column c (= lane & 15) -> cell of the 16-position tile (2 board rows).  ds_read_b128 is served in the lane
 // groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS): columns {0-3,12-15} of one k-chunk share a
@@ -326,8 +335,8 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
 // ---- first layer: input planes (global, NCHW) -> the image.  Its operands are staged INSIDE the (not yet written) image:
 // [512 pos][16 ch] input at OFF_FIN, all 9 tap weight slabs [9][128 co][16 ci] at OFF_FW; the layer's whole output waits in
 // the accumulators (wave = 64 co x 128 positions = 2 x 4 tiles of 32 x 32) until every wave has read its operands. --------
-__device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const uint16_t *__restrict__ x, int64_t board0, int64_t n_boards, int tid,
-                                            uint32_t vm) {
+__device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const Route &rt, const uint16_t *__restrict__ x, int64_t board0, int64_t n_boards,
+                                            int tid, uint32_t vm) {
     const int w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
     char *in = lds + OFF_FIN;
@@ -345,10 +354,12 @@ __device__ __forceinline__ void layer_first(char *lds, const Tower &tw, const ui
         const int64_t b = board0 + (q >> 6);
         uint32_t pk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (b < n_boards) {
-            const uint16_t *px = x + b * tw.cin * 64 + (q & 63);
+            // planes 0..7 and the planes behind them: one (n, cin, 8, 8) array, or a pool row + an (n, cin - 8, 8, 8) array
+            const uint16_t *plo = rt.src_pool ? rt.src_pool + (int64_t)rt.src_slot[b] * 512 + (q & 63) : x + b * tw.cin * 64 + (q & 63);
+            const uint16_t *phi = rt.src_pool ? x + b * (tw.cin - 8) * 64 + (q & 63) : plo + 512;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const uint32_t v = k < tw.cin ? (uint32_t)px[k * 64] : 0u;
+                const uint32_t v = k < tw.cin ? (uint32_t)(k < 8 ? plo[k * 64] : phi[(k - 8) * 64]) : 0u;
                 pk[k >> 1] |= v << ((k & 1) * 16);
             }
         }
@@ -518,12 +529,13 @@ __device__ __forceinline__ void layer_last(char *lds, const Tower &tw, int tid, 
 // the hidden state (global, NCHW, 8 planes) from layer_last's registers: wave -> board, lane -> cell; consecutive lanes write
 // consecutive cells of one plane.  Nothing in the kernel waits on these stores.
 template <int OUT_DT>
-__device__ __forceinline__ void store_hidden(const float (&hv)[8], void *__restrict__ hidden, int64_t board0, int64_t n_boards, int tid) {
+__device__ __forceinline__ void store_hidden(const float (&hv)[8], void *__restrict__ hidden, const Route &rt, int64_t board0, int64_t n_boards, int tid) {
     const int64_t b = board0 + (tid >> 6);
     if (b >= n_boards) return;
+    const int64_t row = dst_row(rt, b);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int64_t o = b * 512 + k * 64 + (tid & 63);
+        const int64_t o = row * 512 + k * 64 + (tid & 63);
         if (OUT_DT == MZ_F32) reinterpret_cast<float *>(hidden)[o] = hv[k];
         else reinterpret_cast<uint16_t *>(hidden)[o] = (uint16_t)(__float_as_uint(hv[k]) >> 16);
     }
@@ -582,7 +594,8 @@ struct Readback {
     float pv;   // this thread's small head parameter (heads_param), requested with the readback
 };
 template <int OUT_DT>
-__device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads &hd, const void *hidden, int64_t tile0, int64_t tstride, int nprev, int tid) {
+__device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads &hd, const void *hidden, const Route &rt, int64_t tile0, int64_t tstride,
+                                               int nprev, int tid) {
     constexpr int NW = Readback<OUT_DT>::NW;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own earlier stores (long complete: a formality that costs nothing here)
 #pragma unroll
@@ -590,7 +603,7 @@ __device__ __forceinline__ void readback_issue(Readback<OUT_DT> &rb, const Heads
         const int i = tid + 512 * r, slot = i / NW;
         const int sl = slot < 8 * nprev ? slot : 0;    // unused slots re-read the batch's first board (valid) and are ignored later
         const int64_t b = (tile0 + (int64_t)(sl >> 3) * tstride) * TILE_BOARDS + (sl & 7);
-        rb.v[r] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(hidden) + b * NW + (i % NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rb.v[r] = __hip_atomic_load(reinterpret_cast<const uint32_t *>(hidden) + dst_row(rt, b) * NW + (i % NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     rb.pv = heads_param(hd, tid);
 }
@@ -738,8 +751,9 @@ __device__ __forceinline__ void heads_batch(char *lds, const Heads &hd, const Re
 
 // one 8-board tile through the convolution tower: first layer, three residual blocks, last layer, hidden state stored
 template <int OUT_DT>
-__device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const Heads &hd, const uint16_t *__restrict__ x, void *__restrict__ hidden,
-                                           int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride, float (&hv)[8]) {
+__device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const Heads &hd, const Route &rt, const uint16_t *__restrict__ x,
+                                           void *__restrict__ hidden, int64_t n_boards, int64_t tile, int &tid, Readback<OUT_DT> &rb, int nprev, int64_t tstride,
+                                           float (&hv)[8]) {
     Tower tw = tw_;
     if (tw.stamps) tw.stamps += tile * 24;   // this tile's row of the diagnostics array
     const uint32_t vm = halo_mask(tid & 31);
@@ -750,7 +764,7 @@ __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const He
     f32x4 bv[4];   // bias of the first mid layer in the K loop's accumulator layout (see layer_mid)
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(tw.b_mid + 64 * ((tid >> 6) & 1) + 16 * i + 4 * ((tid & 63) >> 4));
-    layer_first(lds, tw, x, board0, n_boards, tid, vm);
+    layer_first(lds, tw, rt, x, board0, n_boards, tid, vm);
     MZ_STAMP(tw, 1);
     MZ_STAMP(tw, 2);
     acc16_t acc[4][8];   // the K loops' accumulators: each layer's epilogue leaves the next layer's starting values in them
@@ -768,12 +782,12 @@ __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const He
         MZ_STAMP(tw, 6 + 4 * blk);
     }
     asm volatile("" : "+v"(tid));   // lane-derived addresses of the phases below are computed HERE, not held across the K loops
-    if (nprev >= 0) readback_issue<OUT_DT>(rb, hd, hidden, tile - nprev * tstride, tstride, nprev, tid);   // the heads follow this tile
+    if (nprev >= 0) readback_issue<OUT_DT>(rb, hd, hidden, rt, tile - nprev * tstride, tstride, nprev, tid);   // the heads follow this tile
     layer_last<OUT_DT>(lds, tw, tid, hv);
     MZ_STAMP(tw, 15);
     // a tile that the heads follow stores its hidden state AFTER them (its stores would otherwise sit in the memory queue in
     // front of the heads' weight loads, and a wait for those would wait for the stores' completion too)
-    if (nprev < 0) store_hidden<OUT_DT>(hv, hidden, board0, n_boards, tid);
+    if (nprev < 0) store_hidden<OUT_DT>(hv, hidden, rt, board0, n_boards, tid);
 }
 
 // Persistent grid: one workgroup per CU walks its tiles (tile = blockIdx.x, += gridDim.x), which saves the workgroup
@@ -782,7 +796,7 @@ __device__ __forceinline__ void tower_tile(char *lds, const Tower &tw_, const He
 // (scalar loads, cached) through a pointer the compiler cannot see through, and the lane id is laundered the same way, so no
 // address or pointer computed for one tile stays live into the K loops of the next (a plain loop spills: 20 pointers and
 // the per-lane LDS addresses of every phase would be hoisted and held).
-struct KArgs { Tower tw; Heads hd; const uint16_t *x; void *hidden; int64_t n_boards; };
+struct KArgs { Tower tw; Heads hd; const uint16_t *x; void *hidden; int64_t n_boards; Route rt; };
 typedef const __attribute__((address_space(4))) char *kptr_t;
 template <class T>
 __device__ __forceinline__ T karg(kptr_t base, size_t off) { return *reinterpret_cast<const __attribute__((address_space(4))) T *>(base + off); }
@@ -812,15 +826,17 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
         // the heads run once per batch of two tiles (heads_batch): after this tile if it is the batch's second or the workgroup's last
         const bool heads_now = hd.policy != nullptr && (in_batch == 1 || (tile + gridDim.x) * TILE_BOARDS >= n_boards);
         void *hidden = karg<void *>(ka, offsetof(KArgs, hidden));
+        const Route rt{karg<const uint16_t *>(ka, offsetof(KArgs, rt.src_pool)), karg<const int32_t *>(ka, offsetof(KArgs, rt.src_slot)),
+                       karg<const int32_t *>(ka, offsetof(KArgs, rt.dst_slot)), karg<int64_t>(ka, offsetof(KArgs, rt.dst_stride))};
         Readback<OUT_DT> rb;
         float hv[8];
-        tower_tile<OUT_DT>(lds, tw, hd, karg<const uint16_t *>(ka, offsetof(KArgs, x)), hidden, n_boards, tile, tid, rb, heads_now ? in_batch : -1, gridDim.x, hv);
+        tower_tile<OUT_DT>(lds, tw, hd, rt, karg<const uint16_t *>(ka, offsetof(KArgs, x)), hidden, n_boards, tile, tid, rb, heads_now ? in_batch : -1, gridDim.x, hv);
         ++in_batch;
         if (heads_now) {
             asm volatile("" : "+v"(tid));
             heads_batch<OUT_DT>(lds, hd, rb, hv, n_boards, tile - (int64_t)(in_batch - 1) * gridDim.x, gridDim.x, in_batch, tid,
                                 tw.stamps ? tw.stamps + tile * 24 : nullptr);
-            store_hidden<OUT_DT>(hv, hidden, tile * TILE_BOARDS, n_boards, tid);
+            store_hidden<OUT_DT>(hv, hidden, rt, tile * TILE_BOARDS, n_boards, tid);
             in_batch = 0;
         }
         if (tw.stamps && threadIdx.x == 0) {   // diagnostics: end of this tile (and of its batch's heads, when they ran here)
@@ -834,7 +850,7 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
 }  // namespace
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,
-                        int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream) {
+                        int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream, const Route &rt = Route{nullptr, nullptr, nullptr, 1}) {
     MZ_REQUIRE(w, "%s: null weights", who);
     MZ_REQUIRE(n >= 0, "%s: n < 0", who);
     if (n == 0) return MZ_OK;
@@ -865,7 +881,9 @@ static int launch_tower(const char *who, const mz_tower_weights *w, const mz_hea
         if (cus > 0 && n_wg > cus) n_wg = cus;
     }
     const dim3 grid((unsigned)n_wg), block(512);
-    const KArgs ka{tw, hd, (const uint16_t *)x, hidden, n};
+    MZ_REQUIRE(!rt.src_pool || (rt.src_slot && w->cin > 8), "%s: a source pool needs src_slot and a tower of more than 8 input planes", who);
+    MZ_REQUIRE(rt.dst_slot || rt.dst_stride >= 1, "%s: dst_stride < 1", who);
+    const KArgs ka{tw, hd, (const uint16_t *)x, hidden, n, rt};
     if (hidden_dtype == MZ_F32) hipLaunchKernelGGL(k_tower<MZ_F32>, grid, block, 0, (hipStream_t)stream, ka);
     else hipLaunchKernelGGL(k_tower<MZ_BF16>, grid, block, 0, (hipStream_t)stream, ka);
     MZ_LAUNCH_CHECK("k_tower");
@@ -874,6 +892,14 @@ static int launch_tower(const char *who, const mz_tower_weights *w, const mz_hea
 
 extern "C" int mz_tower_forward(const mz_tower_weights *w, const void *x, void *hidden, int32_t hidden_dtype, int64_t n, void *stream) {
     return launch_tower("mz_tower_forward", w, nullptr, x, hidden, hidden_dtype, nullptr, nullptr, n, stream);
+}
+
+extern "C" int mz_inference_forward_routed(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, const void *src_pool,
+                                           const int32_t *src_slot, void *dst_pool, const int32_t *dst_slot, int64_t dst_stride, int32_t hidden_dtype,
+                                           float *value, float *policy, int64_t n, void *stream) {
+    MZ_REQUIRE(heads, "mz_inference_forward_routed: null heads");
+    return launch_tower("mz_inference_forward_routed", w, heads, x, dst_pool, hidden_dtype, value, policy, n, stream,
+                        Route{(const uint16_t *)src_pool, src_slot, dst_slot, dst_slot ? 1 : dst_stride});
 }
 
 extern "C" int mz_inference_forward(const mz_tower_weights *w, const mz_heads_weights *heads, const void *x, void *hidden, int32_t hidden_dtype,

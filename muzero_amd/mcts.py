@@ -63,7 +63,8 @@ class BatchedMCTS:
         """play_game main.py:75-83: root expansion over legal actions + exploration noise.
         to_play int8 (n,), legal int64 (n,), policy f32 (n,65), hidden (n,8,8,8), noise f64 (n,65) by action.
         device_noise_seed (with noise=None): draw the Dirichlet noise on the device (mz_search_cfg.device_noise)."""
-        self._check(policy, hidden)
+        if hidden is not None:   # (None: the initial inference wrote the roots' hidden states into their pool slots)
+            self._check(policy, hidden)
         cfg = self.cfg
         if device_noise_seed is not None and noise is None:
             cfg = L.SearchCfg.from_buffer_copy(self.cfg)
@@ -77,10 +78,34 @@ class BatchedMCTS:
         L.call("mz_mcts_select", *self._args(), L.dptr(self.net_in), self.n, L.current_stream())
 
     def expand_backup(self, value, policy, hidden):
-        self._check(policy, hidden, value)
+        """hidden None: the new nodes' hidden states are in their pool slots already (routed inference)"""
+        if hidden is not None:
+            self._check(policy, hidden, value)
         self._count()
         L.call("mz_mcts_expand_backup", *self._args(), L.dptr(value), L.dptr(policy), L.dptr(hidden), self.n,
                L.current_stream())
+
+    # ---- routed form: the inference launch reads / writes hidden states in the pool itself (mz_leaf_route) ----
+    def hidden_pool(self):
+        """the pool's hidden region as a (n_trees * max_nodes, 512) tensor of the hidden dtype (a view)"""
+        o, m = self.layout.off_hidden, self.layout.max_nodes
+        eb = self.layout.hidden_elem_bytes
+        return self.pool[o:o + self.n * m * 512 * eb].view(self.hidden_dtype).view(self.n * m, 512)
+
+    def route(self):
+        if getattr(self, "_route", None) is None:
+            self.src_slot = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+            self.dst_slot = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+            self.act_planes = torch.zeros((self.n, 2, 8, 8), dtype=self.hidden_dtype, device=self.device)
+            self._route = L.LeafRoute(self.src_slot.data_ptr(), self.dst_slot.data_ptr(), self.act_planes.data_ptr())
+        return self._route
+
+    def select_routed(self):
+        L.call("mz_mcts_select_routed", *self._args(), C.byref(self.route()), self.n, L.current_stream())
+
+    def backup_select_routed(self, value, policy):
+        self._count()
+        L.call("mz_mcts_backup_select_routed", *self._args(), L.dptr(value), L.dptr(policy), C.byref(self.route()), self.n, L.current_stream())
 
     def backup_select(self, value, policy, hidden):
         """expand_backup of this simulation fused with select of the next one"""

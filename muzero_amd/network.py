@@ -289,6 +289,20 @@ class InferenceEngine:
                L.MZ_BF16, L.dptr(value), L.dptr(policy), n, L.current_stream())
         return value, policy, hidden
 
+    def infer_routed(self, name, x, dst_pool, value, policy, src_pool=None, src_slot=None, dst_slot=None, dst_stride=1):
+        """mz_inference_forward_routed: the same launch with its hidden states read from / written into rows of a pool (the
+        search pool's hidden region) -- x holds only the planes behind the 8 hidden planes when src_pool is given"""
+        L = self._L
+        pk = self._packs[name]
+        n = value.shape[0]
+        planes = pk["cin"] - (8 if src_pool is not None else 0)
+        if x.dtype != torch.bfloat16 or tuple(x.shape) != (n, planes, 8, 8) or not x.is_contiguous():
+            raise L.MzError("routed HIP tower input must be a contiguous bf16 (n,%d,8,8) tensor" % planes)
+        L.call("mz_inference_forward_routed", L.C.byref(pk["struct"]), L.C.byref(self._packs["heads"]["struct"]), L.dptr(x), L.dptr(src_pool),
+               L.dptr(src_slot), L.dptr(dst_pool), L.dptr(dst_slot), int(dst_stride), L.MZ_BF16, L.dptr(value), L.dptr(policy), n,
+               L.current_stream())
+        return value, policy
+
     @torch.no_grad()
     def load_weights(self, state_dict):
         """publish new weights (SharedStorage.save_network -> run_selfplay's load_state_dict,

@@ -155,20 +155,25 @@ class SelfPlayEngine:
         return self.use_graph and self.S > 1 and self._net_out() is not None and os.environ.get("MZ_STEP_GRAPH") != "1"
 
     def _search_body(self, mode):
-        out = self._net_out()
-        v0, p0, h0 = self.net.initial(self._image, out=out)
-        h0 = h0.reshape(self.n, 8, 8, 8)
-        env = self.env
+        """routed: hidden states never leave the node pool -- the inference launch reads the leaf's parent from its slot and
+        writes the new node's state into its slot (mz_inference_forward_routed); the tree kernels copy nothing"""
+        v, p, _ = self._net_out()
+        m, env, net = self.mcts, self.env, self.net
+        pool_h = m.hidden_pool()
+        m.route()
+        net.infer_routed("repr", self._image, pool_h, v, p, dst_stride=m.layout.max_nodes)
         if mode == "device":
-            self.mcts.root_init(env.to_play, env.legal, p0, h0, None, device_noise_seed=self.seed)
+            m.root_init(env.to_play, env.legal, p, None, None, device_noise_seed=self.seed)
         else:
-            self.mcts.root_init(env.to_play, env.legal, p0, h0, self._g_noise if mode == "given" else None)
-        self.mcts.select()
-        for _ in range(self.S - 1):
-            self._sim_step()
-        v, p, h = self._recurrent()
-        L.call("mz_mcts_expand_backup", *self.mcts._args(), L.dptr(v), L.dptr(p), L.dptr(h), self.n, L.current_stream())
-        return self.mcts.root_stats()
+            m.root_init(env.to_play, env.legal, p, None, self._g_noise if mode == "given" else None)
+        m.select_routed()
+        for s in range(self.S):
+            net.infer_routed("dyn", m.act_planes, pool_h, v, p, src_pool=pool_h, src_slot=m.src_slot, dst_slot=m.dst_slot)
+            if s + 1 < self.S:
+                L.call("mz_mcts_backup_select_routed", *m._args(), L.dptr(v), L.dptr(p), L.C.byref(m.route()), self.n, L.current_stream())
+            else:
+                L.call("mz_mcts_expand_backup", *m._args(), L.dptr(v), L.dptr(p), None, self.n, L.current_stream())
+        return m.root_stats()
 
     def _search_graph(self, image, noise, mode, copy):
         env = self.env
