@@ -94,14 +94,105 @@ def muzero_loss(network, batch):
     return p_loss, v_loss
 
 
-def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None, loss_scale=1.0):
+# ---- the same loss, organised for the GPU ---------------------------------------------------------------------------------
+# main.py:247-252 calls the Dynamics and Prediction networks K (+1) times per step, so autograd computes every one of their
+# weight gradients K (+1) times on a batch of B and adds the pieces up: per step ~40 weight-gradient convolutions with their
+# layout transposes, ~120 accumulation adds and ~44 bias reductions, most of them short kernels with idle gaps between them
+# (profiles/r02/train_step_breakdown.txt).  muzero_loss_batched computes the SAME function:
+#   * the prediction heads run ONCE on the (K+1) B hidden states (the heads see each sample independently: no batch norm);
+#   * a Dynamics convolution's weight (and bias) gradient is computed in ONE call over the concatenation of its K uses: the
+#     backward of each use returns only the input gradient and parks (input, grad_output); flush_weight_grads() then runs one
+#     weight-gradient convolution per layer.
+# Same sums in another order: fp32 rounding differences only (tests/test_gpu_train.py holds it to the reference's recorded
+# gradients with the tolerances of the plain form).
+class _ConvDeferW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, conv, sink):
+        ctx.save_for_backward(x, conv.weight)
+        ctx.sink = sink
+        return torch.ops.aten.convolution(x, conv.weight, conv.bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        ctx.sink.append((x, g))
+        return gx, None, None
+
+
+class DeferredWeightGrads:
+    """parks the (input, grad_output) pairs of every use of a convolution during backward; flush() = one weight-gradient call
+    per convolution over the concatenated uses, accumulated into .grad (views of a FlatGradBucket stay views)"""
+
+    def __init__(self):
+        self.sinks = {}
+
+    def conv(self, x, conv):
+        sink = self.sinks.setdefault(id(conv), (conv, []))[1]
+        return _ConvDeferW.apply(x, conv, sink)
+
+    @torch.no_grad()
+    def flush(self):
+        for conv, sink in self.sinks.values():
+            if not sink:
+                continue
+            X = torch.cat([x for x, _ in sink]) if len(sink) > 1 else sink[0][0]
+            G = torch.cat([g for _, g in sink]) if len(sink) > 1 else sink[0][1]
+            has_b = conv.bias is not None
+            _, gw, gb = torch.ops.aten.convolution_backward(G, X, conv.weight, [conv.out_channels] if has_b else None, [1, 1], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, [False, True, has_b])
+            for prm, gr in ((conv.weight, gw), (conv.bias, gb)):
+                if prm is None or gr is None:
+                    continue
+                if prm.grad is None:
+                    prm.grad = gr
+                else:
+                    prm.grad.add_(gr)
+            sink.clear()
+
+
+def _dynamics_deferred(dyn, x, dw):
+    """Dynamics.conv (network.py:113-135) with every convolution's weight gradient deferred"""
+    seq = dyn.conv
+    h = torch.relu(dw.conv(x, seq[0]))
+    for blk in (seq[2], seq[3], seq[4]):
+        t = torch.relu(dw.conv(h, blk.block[0]))
+        h = torch.relu(h + dw.conv(t, blk.block[2]))
+    return torch.relu(dw.conv(h, seq[5]))
+
+
+def muzero_loss_batched(network, batch, dw):
+    """muzero_loss with the heads batched over the unroll and the Dynamics weight gradients deferred into dw
+    (call dw.flush() after backward).  Returns (p_loss, v_loss)."""
+    dev = next(network.parameters()).device
+    image, actions, target_values, target_policies = (torch.as_tensor(x, dtype=torch.float32).to(dev) for x in batch)
+    hidden = network.representation(image)
+    hiddens = [hidden]
+    for action in actions:
+        hidden = _dynamics_deferred(network.dynamics, torch.cat((hidden, action), dim=1), dw)
+        hiddens.append(hidden)
+    K1, B = len(hiddens), image.shape[0]
+    p_policy, p_value = network.prediction(torch.cat(hiddens))        # ((K+1) B, 65), ((K+1) B, 1): rows k * B + b
+    p_policy = p_policy.view(K1, B, -1)
+    p_value = p_value.view(K1, B)
+    p_loss = torch.mean(torch.sum(-target_policies * torch.log(p_policy), dim=2))   # mean over (K+1, B) = mean over (B, K+1)
+    v_loss = torch.sum((target_values - p_value) ** 2) / B                          # mean over B of the sum over k
+    return p_loss, v_loss
+
+
+def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None, loss_scale=1.0, batched=None):
     """main.py:230-272.  With `bucket` (FlatGradBucket over network.parameters()) the gradients are
     averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step.
     amp_dtype (e.g. torch.bfloat16): run the forward/backward convolutions under torch.autocast (fp32 master
     weights, gradients and optimiser state stay fp32); None = the reference's fp32 arithmetic.
     loss_scale: data-parallel ranks with UNEQUAL local batches (sharded replay window) pass b_local * world / B_global, so the
     mean over ranks of the scaled gradients is the gradient of the mean over the global batch; batch=None = this rank drew
-    no sample this step (it contributes a zero gradient and still joins the all-reduce).  The returned losses are unscaled."""
+    no sample this step (it contributes a zero gradient and still joins the all-reduce).  The returned losses are unscaled.
+    batched: use muzero_loss_batched (heads once over the unroll, one weight-gradient call per Dynamics convolution); default:
+    on a GPU in fp32, the plain reference-shaped muzero_loss elsewhere."""
     if bucket is not None:
         bucket.zero()
     else:
@@ -118,9 +209,14 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
                 p_loss, v_loss = muzero_loss(network, batch)
             p_loss, v_loss = p_loss.float(), v_loss.float()
         else:
-            p_loss, v_loss = muzero_loss(network, batch)
+            if batched is None:   # the GPU organisation where it pays: on a GPU, in the reference's fp32 arithmetic
+                batched = next(network.parameters()).is_cuda and os.environ.get("MZ_TRAIN_PLAIN") != "1"
+            dw = DeferredWeightGrads() if batched else None
+            p_loss, v_loss = muzero_loss_batched(network, batch, dw) if batched else muzero_loss(network, batch)
         total = p_loss + v_loss
         (total if loss_scale == 1.0 else total * float(loss_scale)).backward()
+        if amp_dtype is None and dw is not None:
+            dw.flush()
     if bucket is not None:
         bucket.all_reduce_mean(group)
     elif _dist_on(group):
