@@ -270,9 +270,17 @@ def bench_loop(args, device, dtype):
     losses = lp.generation(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the same generation with the training steps on a second stream while the games are played (main.py:32-37)
+    lp.generation(2, overlap=True)        # warm-up of the second stream's allocations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lp.generation(steps, overlap=True)
+    torch.cuda.synchronize()
+    dto = time.perf_counter() - t0
     config.num_unroll_steps = 3
     return {"games": g, "simulations": args.selfplay_sims, "train_steps": steps, "batch": args.train_batch,
             "unroll_steps": args.train_unroll, "seconds_per_generation": dt, "games_per_sec": g / dt,
+            "overlapped_seconds_per_generation": dto, "overlapped_games_per_sec": g / dto,
             "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 
 

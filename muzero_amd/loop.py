@@ -13,6 +13,12 @@ torch.distributed job (RCCL on the GPUs; none needed for one GPU) alternates, pe
      storage a captured hipGraph replays against) -- SharedStorage.save_network / run_selfplay's
      load_state_dict (main.py:60-61, 216-221) without Ray.
 
+`generation(train_steps, overlap=True)` runs 1 and 3 AT THE SAME TIME, as the reference's actors and trainer do (main.py:32-37):
+the training steps are enqueued on a second HIP stream, a few per real move, against the window as it stood before this
+generation (its games are saved, and the weights published, at the generation boundary -- the serving engine holds its own copy
+of the weights, so nothing a search replays is written under it).  The inference kernel fills every CU, so the two streams
+share the GPU kernel by kernel: what the overlap buys is the training step's idle time between its short dependent kernels.
+
 All ranks draw the same (game, position) pairs from `random` (seeded identically, main.py:19) and
 take disjoint slices of them, so an N-GPU run trains on exactly the batch a 1-GPU run would.
 """
@@ -64,38 +70,84 @@ class MuZeroLoop:
             window //= self.world
         self.replay = ReplayBuffer(self.device, window_size=window, batch_size=self.batch_size if replay_mode == "replicated" else 1)
         self.losses = []
+        self.train_stream = None
 
-    def generation(self, train_steps):
-        """one self-play round + `train_steps` updates; returns the losses of this generation"""
-        rec = self.selfplay.play_games()
-        K = config.num_unroll_steps
-        out = []
+    def _n_global(self):
+        return self.replay.buffer_size * (self.world if self.replay_mode == "sharded" else 1)
+
+    def _save(self, rec):
         if self.replay_mode == "replicated":
             for part in gather_game_records(rec, self.group):   # one dict per rank, in game-id order (this rank's own records when alone)
                 self.replay.save_games(part, lengths=rec.length)
-            n_global = self.replay.buffer_size
         else:
             self.replay.save_games(rec)                          # no collective: the window is sharded by game id
-            n_global = self.replay.buffer_size * self.world
-        if n_global >= self.batch_size:                          # ReplayBuffer.ready(), utilities.py:65-69, on the global window
-            shard = self.batch_size // self.world
-            for _ in range(train_steps):
-                idx = random.sample(range(n_global), self.batch_size)                      # utilities.py:76 (same draws on every rank)
-                if self.replay_mode == "replicated":
-                    pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
-                    sl = slice(self.rank * shard, (self.rank + 1) * shard)
-                    batch, scale = self.replay.sample_batch(K, idx[sl], pos[sl]), 1.0
-                else:
-                    # every game of this engine lasts exactly max_moves moves (selfplay.py), so all ranks can make the
-                    # reference's position draw (utilities.py:104) for games they do not hold
-                    pos = [random.randint(0, rec.length - K) for _ in idx]
-                    mine = [(li, p) for (r, li), p in ((owner_of_global_game(i, self.games_per_rank, self.world), p) for i, p in zip(idx, pos))
-                            if r == self.rank]
-                    batch = self.replay.sample_batch(K, [li for li, _ in mine], [p for _, p in mine]) if mine else None
-                    scale = len(mine) * self.world / self.batch_size
-                out.append(T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group, loss_scale=scale))
-            self.storage.save_network(self.network.state_dict())
-            self.infer.load_weights(self.storage.get_network())
+
+    def _train_step(self):
+        """one sample_batch + update_weights on the current stream and the current window; returns the two losses"""
+        K = config.num_unroll_steps
+        n_global = self._n_global()
+        shard = self.batch_size // self.world
+        idx = random.sample(range(n_global), self.batch_size)                      # utilities.py:76 (same draws on every rank)
+        if self.replay_mode == "replicated":
+            pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
+            sl = slice(self.rank * shard, (self.rank + 1) * shard)
+            batch, scale = self.replay.sample_batch(K, idx[sl], pos[sl]), 1.0
+        else:
+            # every game of this engine lasts exactly max_moves moves (selfplay.py), so all ranks can make the
+            # reference's position draw (utilities.py:104) for games they do not hold
+            pos = [random.randint(0, int(self.selfplay.cfg.max_moves) - K) for _ in idx]
+            mine = [(li, p) for (r, li), p in ((owner_of_global_game(i, self.games_per_rank, self.world), p) for i, p in zip(idx, pos))
+                    if r == self.rank]
+            batch = self.replay.sample_batch(K, [li for li, _ in mine], [p for _, p in mine]) if mine else None
+            scale = len(mine) * self.world / self.batch_size
+        return T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group, loss_scale=scale)
+
+    def _publish(self):
+        self.storage.save_network(self.network.state_dict())
+        self.infer.load_weights(self.storage.get_network())
+
+    def generation(self, train_steps, overlap=False, order="selfplay_first"):
+        """one self-play round + `train_steps` updates; returns the losses of this generation.
+        overlap=False, order="selfplay_first": self-play, save the games, train on the window that holds them, publish.
+        overlap=True: the training steps run on a second stream WHILE the games are played, on the window as it stood before
+        this generation; games saved and weights published at the boundary.  order="train_first" (overlap=False) executes that
+        same dataflow one after the other -- what the overlapped form is tested against."""
+        out = []
+        ready = self._n_global() >= self.batch_size              # ReplayBuffer.ready(), utilities.py:65-69, on the global window
+        if overlap:
+            if self.train_stream is None:
+                self.train_stream = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream()
+            self.train_stream.wait_stream(main)                  # the window and the weights as the previous generation left them
+            done = [0]
+            T_moves = int(self.selfplay.cfg.max_moves)
+
+            def on_move(t):
+                # spread the steps over the game's moves; enqueued behind the move's own launches, on the other stream
+                want = train_steps * (t + 1) // T_moves if ready else 0
+                with torch.cuda.stream(self.train_stream):
+                    while done[0] < want:
+                        out.append(self._train_step())
+                        done[0] += 1
+
+            rec = self.selfplay.play_games(on_move=on_move)
+            main.wait_stream(self.train_stream)
+            self._save(rec)
+            if out:
+                self._publish()
+        elif order == "train_first":
+            if ready:
+                out = [self._train_step() for _ in range(train_steps)]
+            rec = self.selfplay.play_games()
+            self._save(rec)
+            if out:
+                self._publish()
+        else:
+            rec = self.selfplay.play_games()
+            self._save(rec)
+            if self._n_global() >= self.batch_size:
+                out = [self._train_step() for _ in range(train_steps)]
+                self._publish()
         self.losses.extend(out)
         return out
 

@@ -240,9 +240,10 @@ class SelfPlayEngine:
         return self.mcts.root_stats()
 
     # ---- whole games (main.py:69-92) -----------------------------------------------------------------
-    def play_games(self, noise=None, u=None, max_moves=None):
+    def play_games(self, noise=None, u=None, max_moves=None, on_move=None):
         """Play n games from the opening. noise: optional (moves, n, 65) f64 by action; u: optional
-        (moves, n) f64 uniforms for the sampled moves (both default to the engine's generator)."""
+        (moves, n) f64 uniforms for the sampled moves (both default to the engine's generator).
+        on_move(t): called on the host once move t's work is enqueued (MuZeroLoop enqueues training steps on another stream there)."""
         T = int(max_moves if max_moves is not None else self.cfg.max_moves)
         rec = GameRecords(self.n, self.device, T, max_visits=self.S)
         env = self.env
@@ -267,6 +268,8 @@ class SelfPlayEngine:
             rec.hist_white[t + 1].copy_(env.white)
             rec.hist_black[t + 1].copy_(env.black)
             rec.length = t + 1
+            if on_move is not None:
+                on_move(t)
         rec.done = env.done.clone()
         # one sync per call: a move the env rejected (the reference would assert, reversi.py:143-144) or a tree that ran
         # out of pool must not flow into the replay window as a silently corrupt trajectory

@@ -50,3 +50,42 @@ def test_sharded_window_equals_replicated_on_one_rank():
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-6)
     finally:
         config.num_unroll_steps = old
+
+
+def test_overlapped_generation_equals_the_same_dataflow_in_series():
+    """generation(overlap=True) -- training on a second stream while the games are played, as the reference's actors and
+    trainer run at the same time (main.py:32-37) -- against the same dataflow executed one after the other
+    (order="train_first": train on the window as it stood, play, save, publish).  Generations 1 and 2 play with the initial
+    weights in both forms, so their games must be IDENTICAL and the training steps that ran beside generation 2 saw identical
+    data; from generation 3 on the games are played with trained weights, and MIOpen's weight-gradient kernels do not sum in
+    a fixed order (a last-bit difference can flip a bf16 rounding of a served weight), so only the losses are compared."""
+    from muzero_amd import config
+    from muzero_amd.loop import MuZeroLoop
+    old = config.num_unroll_steps
+    config.num_unroll_steps = 3
+    try:
+        runs = []
+        for overlap in (False, True):
+            loop = MuZeroLoop(64, num_simulations=6, window_size=128, batch_size=32, infer_dtype=torch.bfloat16)
+            kw = dict(overlap=True) if overlap else dict(order="train_first")
+            assert loop.generation(4, **kw) == []        # window empty: nothing to train on yet
+            l2 = loop.generation(4, **kw)
+            torch.cuda.synchronize()
+            games12 = loop.replay.actions.clone()
+            # published at the boundary, after the last training step: the serving copy is the trained weights, bf16-rounded
+            for a, b in zip(loop.infer.net.state_dict().values(), loop.network.state_dict().values()):
+                assert torch.equal(a, b.to(a.dtype))
+            l3 = loop.generation(7, **kw)
+            l4 = loop.generation(3, **kw)
+            torch.cuda.synchronize()
+            runs.append(dict(l2=[(float(p), float(v)) for p, v in l2], l3=[(float(p), float(v)) for p, v in l3],
+                             l4=[(float(p), float(v)) for p, v in l4], games12=games12, steps=loop.network.steps,
+                             size=loop.replay.buffer_size))
+        a, b = runs
+        assert a["steps"] == b["steps"] == 14 and a["size"] == b["size"] == 128
+        assert len(a["l2"]) == 4 and len(a["l3"]) == 7 and len(a["l4"]) == 3
+        assert torch.equal(a["games12"], b["games12"])
+        assert np.allclose(a["l2"], b["l2"], rtol=1e-4) and np.allclose(a["l3"], b["l3"], rtol=1e-3)
+        assert np.allclose(a["l4"], b["l4"], rtol=5e-2)
+    finally:
+        config.num_unroll_steps = old
