@@ -75,6 +75,13 @@ int mz_env_step(uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *step
                 uint64_t *legal, const uint8_t *action, int8_t *reward, uint8_t *status, int64_t n,
                 void *stream);
 
+/* Environment.step (reversi.py:130-180) on a packed per-game record: the same rules and quirks as mz_env_step, with the six
+ * byte-wide fields in ONE 32-bit word per game, so every stream of the kernel moves 4 or 8 bytes per lane:
+ *   meta: bits 0-6 steps | bit 7 WHITE to move (else BLACK) | bit 8 done | bits 9-15 the action to play, 0..64 (in) |
+ *         bits 16-17 reward + 1 (out) | bits 18-19 status MZ_ST_* (out)
+ * black / white / legal as in mz_env_step; a refused step (MZ_ST_ILLEGAL / MZ_ST_DONE) leaves the state untouched. */
+int mz_env_step_packed(uint64_t *black, uint64_t *white, uint64_t *legal, uint32_t *meta, int64_t n, void *stream);
+
 /* BASELINE.json config 2: games [game0, game0+n) played from the opening for n_steps steps with
  * uniformly random legal moves (counter-based RNG keyed (seed, game, step); k-th legal bit in
  * ascending index), state held in registers for the whole game.  voluntary != 0 also

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mz_env_reset": [_p] * 6 + [_i64, _p],
     "mz_env_legal_mask": [_p] * 4 + [_i64, _p],
     "mz_env_step": [_p] * 9 + [_i64, _p],
+    "mz_env_step_packed": [_p, _p, _p, _p, _i64, _p],
     "mz_env_random_playout": [_u64, _u64, _i64, _i32, _i32] + [_p] * 9 + [_p],
     "mz_env_random_action": [_u64, _u64, _i32, _p, _p, _i64, _p],
     "mz_action_encode": [_p, _p, _p, _i32, _i64, _p],

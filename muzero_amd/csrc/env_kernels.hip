@@ -218,6 +218,34 @@ __global__ void __launch_bounds__(256) k_env_step(uint64_t *black, uint64_t *whi
     }
 }
 
+// the same step on a PACKED per-game record: the six byte-wide streams of k_env_step (to_play, steps, done, action, reward,
+// status: 64-byte requests per wave) become one u32 word (256-byte requests), next to the three u64 words.
+//   meta: bits 0-6 steps | bit 7 WHITE to move | bit 8 done | bits 9-15 the action to play (in) | bits 16-17 reward + 1 (out) |
+//         bits 18-19 status (out)
+__global__ void __launch_bounds__(256) k_env_step_packed(uint64_t *black, uint64_t *white, uint64_t *legal, uint32_t *meta, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = meta[i];
+    EnvState s;
+    s.black = black[i];
+    s.white = white[i];
+    s.steps = (int)(m & 127u);
+    s.to_play = (m >> 7) & 1u ? 1 : -1;
+    s.done = (int)((m >> 8) & 1u);
+    s.legal = 0;
+    int rw;
+    bool turn;
+    const int st = env_step(s, (int)((m >> 9) & 127u), rw, turn);
+    uint32_t out = m & 0xFFFFu;                                  // a refused step leaves the state as it was
+    if (st == MZ_ST_OK) {
+        black[i] = s.black;
+        white[i] = s.white;
+        if (turn) legal[i] = s.legal;
+        out = (uint32_t)s.steps | (s.to_play == 1 ? 128u : 0u) | ((uint32_t)s.done << 8) | (m & 0xFE00u);
+    }
+    meta[i] = out | ((uint32_t)(rw + 1) << 16) | ((uint32_t)st << 18);
+}
+
 template <bool DIGEST, bool LOG>
 __global__ void __launch_bounds__(256) k_env_random_playout(uint64_t seed, uint64_t game0, int64_t n, int n_steps, int voluntary,
                                                             uint64_t *black, uint64_t *white, int8_t *to_play, uint8_t *steps,
@@ -346,6 +374,15 @@ extern "C" int mz_env_step(uint64_t *black, uint64_t *white, int8_t *to_play, ui
     hipLaunchKernelGGL(k_env_step, dim3(mz_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, black, white, to_play, steps, done,
                        legal, action, reward, status, n);
     MZ_LAUNCH_CHECK("k_env_step");
+    return MZ_OK;
+}
+
+extern "C" int mz_env_step_packed(uint64_t *black, uint64_t *white, uint64_t *legal, uint32_t *meta, int64_t n, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_env_step_packed: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(black && white && legal && meta, "mz_env_step_packed: null pointer");
+    hipLaunchKernelGGL(k_env_step_packed, dim3(mz_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, black, white, legal, meta, n);
+    MZ_LAUNCH_CHECK("k_env_step_packed");
     return MZ_OK;
 }
 

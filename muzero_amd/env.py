@@ -40,6 +40,25 @@ class BatchedEnv:
                L.current_stream())
         return self.reward, self.status
 
+    # ---- the packed form: to_play / steps / done / action / reward / status in one int32 word per game (mz_env_step_packed) ----
+    def pack_meta(self, action):
+        """meta word of every game for playing `action` (uint8 (n,)): bits 0-6 steps | 7 WHITE to move | 8 done | 9-15 action"""
+        return (self.steps.to(torch.int32) | ((self.to_play == 1).to(torch.int32) << 7) | (self.done.to(torch.int32) << 8) |
+                (action.to(torch.int32) << 9)).contiguous()
+
+    def step_packed(self, meta):
+        """Environment.step on the packed record, in place (boards, legal, meta).  Returns (reward int8, status uint8) unpacked
+        from the word and refreshes to_play / steps / done from it."""
+        if meta.dtype != torch.int32 or meta.numel() != self.n:
+            raise L.MzError("meta must be an int32 tensor of %d elements" % self.n)
+        L.call("mz_env_step_packed", L.dptr(self.black), L.dptr(self.white), L.dptr(self.legal), L.dptr(meta), self.n, L.current_stream())
+        self.steps.copy_((meta & 127).to(torch.uint8))
+        self.to_play.copy_(torch.where((meta >> 7) & 1 == 1, 1, -1).to(torch.int8))
+        self.done.copy_(((meta >> 8) & 1).to(torch.uint8))
+        self.reward.copy_((((meta >> 16) & 3) - 1).to(torch.int8))
+        self.status.copy_(((meta >> 18) & 3).to(torch.uint8))
+        return self.reward, self.status
+
     def legal_mask(self):
         """recompute legal placements for the side to move (update_legal_actions, reversi.py:119-126)"""
         out = torch.empty_like(self.legal)

@@ -192,3 +192,43 @@ def test_features_vs_oracle_and_fixture(menv, golden_dir):
     for gi, idx, want in zip(fx["img_game"], fx["img_index"], fx["img"]):
         img = menv.make_image(hwd, hbd, int(idx), g).cpu().numpy()[gi]
         assert (img == want).all()
+
+
+def test_packed_step_equals_step_and_oracle(menv):
+    """mz_env_step_packed (to_play / steps / done / action / reward / status in one u32 word per game) against mz_env_step on
+    1,048,576 random games step by step, and against the oracle on arbitrary positions with arbitrary actions (legal,
+    illegal, pass, out of range, finished games)"""
+    n, seed = 1 << 20, 99
+    a = menv.BatchedEnv(n)
+    b = menv.BatchedEnv(n)
+    act = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for t in range(60):
+        a.random_action(seed, 0, t, out=act)
+        if t % 7 == 3:
+            act[::5] = 64                 # voluntary passes (reversi.py:135-139 accepts them)
+        ra, sa = a.step(act)
+        rb, sb = b.step_packed(b.pack_meta(act))
+        assert torch.equal(ra, rb) and torch.equal(sa, sb), t
+    for x, y in ((a.black, b.black), (a.white, b.white), (a.legal, b.legal), (a.to_play, b.to_play), (a.steps, b.steps), (a.done, b.done)):
+        assert bool((x == y).all())
+    # arbitrary positions / actions vs the oracle (the refused cases leave the state untouched)
+    rng = np.random.default_rng(8)
+    n = 100000
+    occ = rng.integers(0, 2**63, n, dtype=np.uint64) & rng.integers(0, 2**63, n, dtype=np.uint64)
+    col = rng.integers(0, 2**63, n, dtype=np.uint64)
+    black, white = occ & col, occ & ~col
+    to_play = rng.choice(np.array([-1, 1], np.int8), n)
+    steps = rng.integers(0, 61, n).astype(np.uint8)
+    done = (rng.integers(0, 8, n) == 0).astype(np.uint8)
+    action = rng.integers(0, 67, n).astype(np.uint8)
+    olegal = O.legal_mask(black, white, to_play)
+    o = O.EnvBatch(n)
+    o.black[:], o.white[:], o.to_play[:], o.steps[:], o.done[:], o.legal[:] = black, white, to_play, steps, done, olegal
+    e = menv.BatchedEnv(n)
+    e.black.copy_(dev(black)); e.white.copy_(dev(white)); e.to_play.copy_(dev(to_play)); e.steps.copy_(dev(steps))
+    e.done.copy_(dev(done)); e.legal.copy_(dev(olegal.view(np.int64)))
+    reward, status = e.step_packed(e.pack_meta(dev(action)))
+    orw, ost = o.step(action)
+    assert (status.cpu().numpy() == ost).all() and (reward.cpu().numpy() == orw).all()
+    assert_state(e, o)
+    assert (ost == 0).sum() > 1000 and (ost == 1).sum() > 1000 and (ost == 2).sum() > 1000
