@@ -497,9 +497,15 @@ static void sustain10(const char *name, const uint4 *src, float *out, long long 
 
 int main10(const uint4 *src, float *out, long long *cyc) {
     run10<false, 7, 4>("builtin DMA at the end", src, out, cyc);
+    run10<false, 5, 4>("builtin DMA behind j = 5", src, out, cyc);
+    run10<true, 7, 4>("asm DMA at the end", src, out, cyc);
+    run10<true, 5, 4>("asm DMA behind j = 5", src, out, cyc);
     run10<true, 0, 4>("asm DMA behind j = 0", src, out, cyc);
+    run10<true, 7, 4, 8, true>("asm DMA at the end, lgkmcnt(0) at the barrier", src, out, cyc);
     run10<false, 3, 4, 4>("builtin DMA at the end", src, out, cyc);
+    run10<true, 3, 4, 4>("asm DMA at the end", src, out, cyc);
     run10<true, 0, 4, 4>("asm DMA behind j = 0", src, out, cyc);
+    run10<true, 3, 4, 4, true>("asm DMA at the end, lgkmcnt(0) at the barrier", src, out, cyc);
     // random operands
     {
         std::vector<unsigned short> h(65536 * 8);
