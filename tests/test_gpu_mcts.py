@@ -123,11 +123,18 @@ def _roots(n, seed):
     return e, hw, hb, lens.astype(np.int32)
 
 
-@pytest.mark.parametrize("n,S,mode,tie_lowest,negamax", [(4096, 50, "hash", False, False), (512, 100, "sat", False, False),
-                                                         (512, 60, "hash", True, False), (512, 60, "hash", False, True)])
-def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest, negamax):
+# the knobs of the bulk reference verdict (tests/golden/bulk_mcts_verdict.json: the oracle under exactly these settings equals the
+# reference on 10,240 searches): known_bounds None / replaced / non-representable (both MinMaxStats kinds of ucb_score's
+# normalize stay live deep into the search), discounts, deep and saturated trees
+@pytest.mark.parametrize("n,S,mode,tie_lowest,negamax,bounds,discount", [
+    (4096, 50, "hash", False, False, (-1, 1), 1.0), (512, 100, "sat", False, False, (-1, 1), 1.0),
+    (512, 60, "hash", True, False, (-1, 1), 1.0), (512, 60, "hash", False, True, (-1, 1), 1.0),
+    (512, 60, "hash", False, False, None, 1.0), (512, 100, "const", False, False, None, 0.9),
+    (512, 60, "hash", False, False, (-0.25, 0.3), 0.997), (512, 60, "uniform", False, False, None, 1.0),
+    (256, 200, "hash", False, False, (-0.1, 0.7), 0.9), (512, 60, "sat", False, True, None, 0.997)])
+def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest, negamax, bounds, discount):
     """BASELINE config 3 size (4096 trees x 50 sims) on HashNet, fused backup+select kernel:
-    every tree's visits / W / root value / per-sim leaf identical to the C oracle."""
+    every tree's visits / W / root value / per-sim leaf identical to the C oracle -- and the same across the search's knobs."""
     from muzero_amd import env as menv
     from muzero_amd.mcts import BatchedMCTS
     e, hw, hb, lens = _roots(n, 4242)
@@ -139,7 +146,7 @@ def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest, negamax):
     for g in range(n):
         acts = [a for a in range(64) if (int(e.legal[g]) >> a) & 1] or [64]
         noise[g, acts] = rng.dirichlet([0.03] * len(acts))
-    cfg = Cfg(tie_break_lowest=tie_lowest, negamax_value=negamax)
+    cfg = Cfg(tie_break_lowest=tie_lowest, negamax_value=negamax, known_bounds=bounds, discount=discount)
     m = BatchedMCTS(n, S, cfg=cfg)
     m.root_init(dev(e.to_play), dev(e.legal), p0.contiguous(), h0.contiguous(), dev(noise))
     leaf_a = np.zeros((n, S), np.uint8); depth = np.zeros((n, S), np.int32)
@@ -157,14 +164,14 @@ def test_bulk_parity_vs_oracle(n, S, mode, tie_lowest, negamax):
     imgs = img.cpu().numpy()
     bad = 0
     for g in range(n):
-        t = O.Tree(S, tie_lowest=tie_lowest, negamax=negamax)
+        t = O.Tree(S, tie_lowest=tie_lowest, negamax=negamax, known_bounds=bounds, discount=discount)
         _, odepth, oleaf = t.search_hashnet(e.to_play[g], e.legal[g], int(e.legal[g] == 0), noise[g], R.hashnet_image_hash(imgs[g]), R.MODES[mode], S)
         ov, ow, op, orn, orv = t.root_stats()
         ok = ((visits[g] == ov).all() and wsum[g].view(np.uint32).tolist() == ow.view(np.uint32).tolist() and (prior[g] == op).all()
               and root_value[g].view(np.uint32) == np.float32(orv).view(np.uint32) and (leaf_a[g] == oleaf).all() and (depth[g] == odepth).all())
         bad += not ok
     assert bad == 0, "%d of %d trees differ from the oracle" % (bad, n)
-    assert depth.max() >= 3
+    assert depth.max() >= (2 if mode == "uniform" else 3)   # (all-equal priors and values: a broad, shallow tie-break tree)
 
 
 def test_config4_size_properties_and_sampled_parity():
