@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-trees", type=int, default=4096)
     ap.add_argument("--train-batch", type=int, default=512, help="config.py:34 batch_size for the training leg (0 = skip)")
     ap.add_argument("--train-unroll", type=int, default=5, help="K (BASELINE configs[4]: 5; config.py:36: 3)")
+    ap.add_argument("--config4-searches", type=int, default=3, help="searches of the 8192 x 100 leg (0 = skip)")
     ap.add_argument("--loop-train-steps", type=int, default=20, help="training steps of the whole-loop leg (one generation)")
     return ap.parse_args()
 
@@ -537,6 +538,25 @@ def main():
                 out["train"] = bench_train(args, device, rec)
                 del sp, net_sp, rec
                 out["loop"] = bench_loop(args, device, dtype)
+        # ---- BASELINE configs[3] per-GPU size: 8192 trees x 100 simulations (what each of 8 GPUs runs in the sharded config)
+        if args.config4_searches > 0 and getattr(net, "tower", "") == "hip":
+            n4, S4 = 8192, 100
+            torch.manual_seed(1261)
+            net4 = InferenceEngine(Network(), n4, dtype, tower=args.tower)
+            eng4 = SelfPlayEngine(n4, net4, num_simulations=S4, device=device, use_graph=not args.no_graph, seed=1261 + rank)
+            roots4, hw4, hb4, idx4 = make_roots(n4, 1261, game0, device)
+            eng4.env = roots4
+            make_image(hw4, hb4, idx4, n4, dtype, out=eng4._image)
+            eng4.search(eng4._image, copy=False)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(args.config4_searches):
+                eng4.search(eng4._image, copy=False)
+            torch.cuda.synchronize()
+            dt4 = (time.perf_counter() - t4) / args.config4_searches
+            out["config4_per_gpu"] = {"trees": n4, "simulations": S4, "ms_per_search": dt4 * 1e3, "simulations_per_sec": n4 * S4 / dt4,
+                                      "note": "BASELINE configs[3] (65,536 games x 100 simulations over 8 GPUs) as one GPU's share"}
+            del eng4, net4, roots4, hw4, hb4
         # ---- reference-precision companion (network.py:146-163 is fp32): the same searches with fp32 inference through
         # PyTorch-ROCm/MIOpen and an fp32 hidden-state pool, and what bf16 serving does to the search's OUTPUT
         bf16_visits, _ = eng.search(image, noise)
