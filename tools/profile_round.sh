@@ -13,7 +13,7 @@ step() { echo "== $*"; }
 step kernel stats
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 bench.py --steps 5 --warmup 2 --skip-extras > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
 cp $(find $O/stats -name "b_kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv || exit 1
-B="python3 bench.py --steps 1 --warmup 1 --selfplay-games 0 --cpu-trees 8 --fp32-steps 0 --train-batch 0"
+B="python3 bench.py --steps 1 --warmup 1 --selfplay-games 0 --cpu-trees 8 --fp32-steps 0 --train-batch 0 --config4-searches 0"
 step pmc fetch
 timeout -s KILL 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- $B > /dev/null 2> $O/pmc_f.err || exit 1
 step pmc write
