@@ -428,6 +428,24 @@ int mz_search_noalloc(const mz_tower_weights *repr, const mz_tower_weights *dyn,
                       const double *noise, int32_t n_sims, int32_t n_trees, int32_t *visits, float *root_value,
                       void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training step: update_weights' loss.backward() (main.py:247-266) for the twelve 3x3, 128 -> 128
+ * convolutions of the two towers (network.py:35-47 inside network.py:49-77 and 113-135), on the matrix cores.
+ *
+ * mz_conv3x3_wgrad: the weight and bias gradient autograd computes for ONE such convolution, summed over up to 8 uses of it
+ * (the K unrolled Dynamics calls of main.py:247-252 share their weights):
+ *     dw[co][ci][ky][kx] (+)= sum_use sum_b sum_{y,x} g[b][co][y][x] * x[b][ci][y+ky-1][x+kx-1]      (zero outside the board)
+ *     db[co]             (+)= sum_use sum_b sum_{y,x} g[b][co][y][x]                                  (db may be NULL)
+ *   x[k], g[k] : the k-th use's input and output gradient, (n_boards[k], 128, 8, 8) f32 NCHW contiguous, 16-byte aligned;
+ *                x, g, n_boards are HOST arrays of n_seg (1..8) entries
+ *   dw         : (128, 128, 3, 3) f32 -- nn.Conv2d.weight's layout; accumulate != 0 adds to what dw / db hold
+ *   workspace  : device scratch of >= mz_conv3x3_wgrad_workspace(sum n_boards) bytes, 16-byte aligned (per-slice partial sums)
+ * Arithmetic: operands rounded to bf16 (round to nearest even), products and sums in f32 on v_mfma_f32_16x16x32_bf16; the
+ * bias gradient is summed from the f32 values.  Sums run in a fixed order: two calls on the same data return the same bits. */
+int64_t mz_conv3x3_wgrad_workspace(int64_t n_boards);
+int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
+                     int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

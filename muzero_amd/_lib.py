@@ -105,6 +105,7 @@ SIGNATURES = {
                           _p, _p, _p],
     "mz_replay_save": [_RP, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _i32, _i64, _i32, _p],
     "mz_replay_sample_batch": [_RP, _p, _p, _i32, _i32, _p, _p, _p, _p, _p],
+    "mz_conv3x3_wgrad": [_p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)
@@ -112,11 +113,13 @@ for _name, _args in SIGNATURES.items():
     _f.restype = C.c_int
 lib.mz_search_workspace_bytes.restype = C.c_int64
 lib.mz_search_workspace_bytes.argtypes = [_i32, _i32]
+lib.mz_conv3x3_wgrad_workspace.restype = C.c_int64
+lib.mz_conv3x3_wgrad_workspace.argtypes = [_i64]
 lib.mz_last_error.restype = C.c_char_p
 lib.mz_last_error.argtypes = []
 lib.mz_version.restype = C.c_int
 lib.mz_version.argtypes = []
-EXPORTS = sorted(list(SIGNATURES) + ["mz_last_error", "mz_version", "mz_search_workspace_bytes"])
+EXPORTS = sorted(list(SIGNATURES) + ["mz_last_error", "mz_version", "mz_search_workspace_bytes", "mz_conv3x3_wgrad_workspace"])
 
 
 def call(name, *args):

@@ -1,0 +1,49 @@
+"""Host side of the training step's hand-written convolution kernels (muzero_amd/csrc/train_kernels.hip).
+
+What autograd computes in loss.backward() (main.py:265-266) for the 3x3, 128 -> 128 convolutions of the two towers
+(network.py:35-47), on the matrix cores: operands rounded to bf16, sums in fp32.  No CPU fallback: host tensors raise."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def _check(t, name):
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 4 or tuple(t.shape[1:]) != (128, 8, 8):
+        raise L.MzError("%s: need contiguous cuda float32 tensors of shape (n, 128, 8, 8), got %s %s on %s" % (name, tuple(t.shape), t.dtype, t.device))
+
+
+def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False):
+    """dw (128,128,3,3) (+)= weight gradient, db (128) (+)= bias gradient of one 3x3 / padding 1 convolution summed over its uses:
+    xs[k] = the k-th use's input, gs[k] = the gradient of its output (mz_conv3x3_wgrad)."""
+    if len(xs) != len(gs) or not 1 <= len(xs) <= 8:
+        raise L.MzError("conv3x3_wgrad: 1..8 (input, grad_output) pairs, got %d / %d" % (len(xs), len(gs)))
+    for x, g in zip(xs, gs):
+        _check(x, "conv3x3_wgrad input")
+        _check(g, "conv3x3_wgrad grad_output")
+        if x.shape[0] != g.shape[0] or x.device != dw.device:
+            raise L.MzError("conv3x3_wgrad: mismatched use")
+    if dw.dtype != torch.float32 or tuple(dw.shape) != (128, 128, 3, 3) or not dw.is_contiguous():
+        raise L.MzError("conv3x3_wgrad: dw must be a contiguous float32 (128,128,3,3) tensor")
+    if db is not None and (db.dtype != torch.float32 or tuple(db.shape) != (128,) or not db.is_contiguous()):
+        raise L.MzError("conv3x3_wgrad: db must be a contiguous float32 (128,) tensor")
+    k = len(xs)
+    total = sum(int(x.shape[0]) for x in xs)
+    need = int(L.lib.mz_conv3x3_wgrad_workspace(total))
+    ws = _workspace(dw.device, need)
+    xp = (C.c_void_p * k)(*[x.data_ptr() for x in xs])
+    gp = (C.c_void_p * k)(*[g.data_ptr() for g in gs])
+    nb = (C.c_int64 * k)(*[int(x.shape[0]) for x in xs])
+    L.call("mz_conv3x3_wgrad", xp, gp, nb, k, L.dptr(dw), L.dptr(db), 1 if accumulate else 0, L.dptr(ws), ws.numel(), L.current_stream())
+    return dw, db

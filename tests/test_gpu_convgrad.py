@@ -1,0 +1,64 @@
+"""The training step's hand-written convolution kernels against PyTorch's fp32 convolution gradients (autograd is what the
+reference runs: main.py:265-266).  Operands are rounded to bf16 inside the kernels, sums are fp32: on inputs that ARE bf16
+values the only difference is the summation order."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_wgrad(xs, gs):
+    X, G = torch.cat(xs).double(), torch.cat(gs).double()
+    w = torch.zeros(128, 128, 3, 3, dtype=torch.float64, device=X.device)
+    _, gw, gb = torch.ops.aten.convolution_backward(G, X, w, [128], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True])
+    return gw, gb
+
+
+def _bf16_values(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("boards", [[1], [3], [7, 2], [512], [5, 130, 64], [512] * 5])
+def test_wgrad_matches_fp64_convolution_backward_on_bf16_values(boards):
+    from muzero_amd.convgrad import conv3x3_wgrad
+    g = torch.Generator(device="cuda").manual_seed(sum(boards))
+    xs = [_bf16_values(torch.randn(n, 128, 8, 8, device="cuda", generator=g)).relu() for n in boards]
+    gs = [_bf16_values(torch.randn(n, 128, 8, 8, device="cuda", generator=g) * 0.1) for n in boards]
+    dw = torch.full((128, 128, 3, 3), 7.0, device="cuda")
+    db = torch.full((128,), 7.0, device="cuda")
+    conv3x3_wgrad(xs, gs, dw, db)
+    gw, gb = _ref_wgrad(xs, gs)
+    # products of bf16 values are exact in fp32; what differs from the fp64 sum is fp32 accumulation over n * 64 terms
+    assert (dw.double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item() + 1e-6
+    assert (db.double() - gb).abs().max().item() <= 2e-5 * gb.abs().max().item() + 1e-6
+    # accumulate: adds to what the outputs hold; deterministic: the same bits again
+    dw2, db2 = dw.clone(), db.clone()
+    conv3x3_wgrad(xs, gs, dw2, db2, accumulate=True)
+    assert torch.equal(dw2, dw + dw) and torch.equal(db2, db + db)
+
+
+def test_wgrad_on_fp32_values_is_within_bf16_rounding():
+    from muzero_amd.convgrad import conv3x3_wgrad
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn(256, 128, 8, 8, device="cuda", generator=g).relu() for _ in range(2)]
+    gs = [torch.randn(256, 128, 8, 8, device="cuda", generator=g) for _ in range(2)]
+    dw, db = torch.empty(128, 128, 3, 3, device="cuda"), torch.empty(128, device="cuda")
+    conv3x3_wgrad(xs, gs, dw, db)
+    gw, gb = _ref_wgrad(xs, gs)
+    # each product carries two roundings of 2^-9 relative, independent over 32,768 terms: a few 1e-3 of the gradient's scale
+    assert (dw.double() - gw).abs().max().item() <= 4e-3 * gw.abs().max().item()
+    assert (dw.double() - gw).norm().item() <= 3e-3 * gw.norm().item()
+    assert (db.double() - gb).abs().max().item() <= 1e-5 * gb.abs().max().item() + 1e-4   # summed from the fp32 values
+
+
+def test_wgrad_refuses_what_it_cannot_do():
+    from muzero_amd import _lib as L
+    from muzero_amd.convgrad import conv3x3_wgrad
+    x = torch.zeros(2, 128, 8, 8, device="cuda")
+    dw = torch.zeros(128, 128, 3, 3, device="cuda")
+    with pytest.raises(L.MzError):
+        conv3x3_wgrad([x.cpu()], [x.cpu()], dw)
+    with pytest.raises(L.MzError):
+        conv3x3_wgrad([x] * 9, [x] * 9, dw)
+    with pytest.raises(L.MzError):
+        conv3x3_wgrad([x.half()], [x.half()], dw)

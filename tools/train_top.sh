@@ -2,7 +2,7 @@
 # top kernels of one training configuration: tools/train_top.sh fp32|bf16
 set -u
 export TMPDIR=/tmp
-O=$PWD/gpurun_out/r2/trainprof; mkdir -p $O; rm -rf $O/run
+O=$PWD/gpurun_out/r03/trainprof; mkdir -p $O; rm -rf $O/run
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/run -o t -- python3 tools/train_prof.py $1 12 > $O/out.txt 2> $O/err.txt || { tail -5 $O/err.txt; exit 1; }
 python3 - $(find $O/run -name "t_kernel_stats.csv" | head -1) <<'PY'
 import csv, sys
