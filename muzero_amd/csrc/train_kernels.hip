@@ -192,8 +192,18 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ 
                                                       float *__restrict__ dw, float *__restrict__ db, int accumulate) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < PART_FLOATS) {
-        float v = 0.f;
-        for (int sl = 0; sl < slices; ++sl) v += partial[(size_t)sl * PART_FLOATS + e];
+        // four interleaved running sums (slices 4 j + q), added ((0 + 1) + (2 + 3)): a fixed order, and four loads in flight
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sl = 0;
+#pragma unroll 2
+        for (; sl + 4 <= slices; sl += 4) {
+            v0 += partial[(size_t)sl * PART_FLOATS + e];
+            v1 += partial[(size_t)(sl + 1) * PART_FLOATS + e];
+            v2 += partial[(size_t)(sl + 2) * PART_FLOATS + e];
+            v3 += partial[(size_t)(sl + 3) * PART_FLOATS + e];
+        }
+        for (; sl < slices; ++sl) v0 += partial[(size_t)sl * PART_FLOATS + e];
+        const float v = (v0 + v1) + (v2 + v3);
         const int lane = e & 63, i = (e >> 6) & 3;
         int rest = e >> 8;
         const int tap = rest % 9;

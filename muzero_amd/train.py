@@ -125,10 +125,13 @@ class _ConvDeferW(torch.autograd.Function):
 
 class DeferredWeightGrads:
     """parks the (input, grad_output) pairs of every use of a convolution during backward; flush() = one weight-gradient call
-    per convolution over the concatenated uses, accumulated into .grad (views of a FlatGradBucket stay views)"""
+    per convolution over its uses, accumulated into .grad (views of a FlatGradBucket stay views).
+    hip=True: the 3x3, 128 -> 128 convolutions' weight and bias gradients come from mz_conv3x3_wgrad (operands rounded to bf16
+    on the matrix cores, fp32 sums, no concatenation) instead of MIOpen's fp32 kernels."""
 
-    def __init__(self):
+    def __init__(self, hip=False):
         self.sinks = {}
+        self.hip = bool(hip)
 
     def conv(self, x, conv):
         sink = self.sinks.setdefault(id(conv), (conv, []))[1]
@@ -139,9 +142,17 @@ class DeferredWeightGrads:
         for conv, sink in self.sinks.values():
             if not sink:
                 continue
+            has_b = conv.bias is not None
+            if self.hip and conv.in_channels == 128 and conv.out_channels == 128 and sink[0][0].is_cuda and sink[0][0].dtype == torch.float32:
+                from .convgrad import conv3x3_wgrad
+                for prm in (conv.weight, conv.bias):
+                    if prm is not None and prm.grad is None:
+                        prm.grad = torch.zeros_like(prm)
+                conv3x3_wgrad([x.contiguous() for x, _ in sink], [g for _, g in sink], conv.weight.grad, conv.bias.grad if has_b else None, accumulate=True)
+                sink.clear()
+                continue
             X = torch.cat([x for x, _ in sink]) if len(sink) > 1 else sink[0][0]
             G = torch.cat([g for _, g in sink]) if len(sink) > 1 else sink[0][1]
-            has_b = conv.bias is not None
             _, gw, gb = torch.ops.aten.convolution_backward(G, X, conv.weight, [conv.out_channels] if has_b else None, [1, 1], [1, 1], [1, 1],
                                                             False, [0, 0], 1, [False, True, has_b])
             for prm, gr in ((conv.weight, gw), (conv.bias, gb)):
@@ -154,13 +165,25 @@ class DeferredWeightGrads:
             sink.clear()
 
 
+def _tower_deferred(blocks, h, dw):
+    for blk in blocks:
+        t = torch.relu(dw.conv(h, blk.block[0]))
+        h = torch.relu(h + dw.conv(t, blk.block[2]))
+    return h
+
+
+def _representation_deferred(rep, image, dw):
+    """Representation (network.py:49-77) with every convolution's weight gradient deferred"""
+    h = rep.conv1(image)                      # its input carries no gradient: plain autograd (a deferred convolution hangs its weight gradient on the input's)
+    h = _tower_deferred(rep.conv2, h, dw)
+    return torch.relu(dw.conv(h, rep.conv3[0]))
+
+
 def _dynamics_deferred(dyn, x, dw):
     """Dynamics.conv (network.py:113-135) with every convolution's weight gradient deferred"""
     seq = dyn.conv
     h = torch.relu(dw.conv(x, seq[0]))
-    for blk in (seq[2], seq[3], seq[4]):
-        t = torch.relu(dw.conv(h, blk.block[0]))
-        h = torch.relu(h + dw.conv(t, blk.block[2]))
+    h = _tower_deferred((seq[2], seq[3], seq[4]), h, dw)
     return torch.relu(dw.conv(h, seq[5]))
 
 
@@ -169,7 +192,7 @@ def muzero_loss_batched(network, batch, dw):
     (call dw.flush() after backward).  Returns (p_loss, v_loss)."""
     dev = next(network.parameters()).device
     image, actions, target_values, target_policies = (torch.as_tensor(x, dtype=torch.float32).to(dev) for x in batch)
-    hidden = network.representation(image)
+    hidden = _representation_deferred(network.representation, image, dw) if dw.hip else network.representation(image)
     hiddens = [hidden]
     for action in actions:
         hidden = _dynamics_deferred(network.dynamics, torch.cat((hidden, action), dim=1), dw)
@@ -183,7 +206,7 @@ def muzero_loss_batched(network, batch, dw):
     return p_loss, v_loss
 
 
-def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None, loss_scale=1.0, batched=None):
+def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype=None, loss_scale=1.0, batched=None, hip_convs=False):
     """main.py:230-272.  With `bucket` (FlatGradBucket over network.parameters()) the gradients are
     averaged over the ranks of `group` by ONE all-reduce between backward and optimizer.step.
     amp_dtype (e.g. torch.bfloat16): run the forward/backward convolutions under torch.autocast (fp32 master
@@ -192,7 +215,10 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
     mean over ranks of the scaled gradients is the gradient of the mean over the global batch; batch=None = this rank drew
     no sample this step (it contributes a zero gradient and still joins the all-reduce).  The returned losses are unscaled.
     batched: use muzero_loss_batched (heads once over the unroll, one weight-gradient call per Dynamics convolution); default:
-    on a GPU in fp32, the plain reference-shaped muzero_loss elsewhere."""
+    on a GPU in fp32, the plain reference-shaped muzero_loss elsewhere.
+    hip_convs: the gradients of the towers' 3x3, 128 -> 128 convolutions through the hand-written matrix-core kernels
+    (muzero_amd/convgrad.py: operands rounded to bf16, fp32 sums; fp32 master weights and optimiser) instead of MIOpen's fp32
+    kernels; implies batched.  False = the reference's fp32 arithmetic."""
     if bucket is not None:
         bucket.zero()
     else:
@@ -211,7 +237,9 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
         else:
             if batched is None:   # the GPU organisation where it pays: on a GPU, in the reference's fp32 arithmetic
                 batched = next(network.parameters()).is_cuda and os.environ.get("MZ_TRAIN_PLAIN") != "1"
-            dw = DeferredWeightGrads() if batched else None
+            if hip_convs:
+                batched = True
+            dw = DeferredWeightGrads(hip=hip_convs) if batched else None
             p_loss, v_loss = muzero_loss_batched(network, batch, dw) if batched else muzero_loss(network, batch)
         total = p_loss + v_loss
         (total if loss_scale == 1.0 else total * float(loss_scale)).backward()

@@ -62,3 +62,34 @@ def test_wgrad_refuses_what_it_cannot_do():
         conv3x3_wgrad([x] * 9, [x] * 9, dw)
     with pytest.raises(L.MzError):
         conv3x3_wgrad([x.half()], [x.half()], dw)
+
+
+def _grads(net, batch, hip):
+    from muzero_amd import train as T
+    for p in net.parameters():
+        p.grad = None
+    dw = T.DeferredWeightGrads(hip=hip)
+    pl, vl = T.muzero_loss_batched(net, batch, dw)
+    (pl + vl).backward()
+    dw.flush()
+    return float(pl.detach()), float(vl.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
+def test_training_gradients_with_hip_convolutions_match_the_fp32_step():
+    """the whole K = 5 unrolled loss: every parameter's gradient with the towers' convolution gradients from the HIP kernels
+    against the fp32 PyTorch/MIOpen step on the same weights and batch (bf16 operand rounding: per-tensor relative L2)"""
+    from muzero_amd.network import Network
+    torch.manual_seed(1261)
+    net = Network().to("cuda")
+    net.train()
+    B, K = 64, 5
+    g = torch.Generator(device="cpu").manual_seed(3)
+    batch = (torch.rand(B, 9, 8, 8, generator=g).round().cuda(), torch.rand(K, B, 2, 8, 8, generator=g).round().cuda(),
+             (torch.rand(K + 1, B, generator=g) * 2 - 1).cuda(), torch.softmax(torch.rand(K + 1, B, 65, generator=g), -1).cuda())
+    pl0, vl0, ref = _grads(net, batch, hip=False)
+    pl1, vl1, got = _grads(net, batch, hip=True)
+    assert abs(pl0 - pl1) <= 2e-3 * abs(pl0) and abs(vl0 - vl1) <= 2e-3 * abs(vl0)
+    worst = max(float((got[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-12)) for k in ref)
+    print("worst per-tensor relative L2 gradient difference: %.3g" % worst)
+    assert worst <= 2e-2
+    assert all(torch.isfinite(v).all() for v in got.values())

@@ -20,7 +20,7 @@ def batch():
     return image, actions, tv, tp
 
 
-def run(name, channels_last=False, benchmark=False, amp=None, batched=None):
+def run(name, channels_last=False, benchmark=False, amp=None, batched=None, hip=False):
     torch.backends.cudnn.benchmark = benchmark
     torch.manual_seed(1261)
     net = Network().to(dev)
@@ -32,12 +32,12 @@ def run(name, channels_last=False, benchmark=False, amp=None, batched=None):
     net.steps = 1
     b = batch()
     for _ in range(4):
-        T.update_weights(opt, net, b, bucket, amp_dtype=amp, batched=batched)
+        T.update_weights(opt, net, b, bucket, amp_dtype=amp, batched=batched, hip_convs=hip)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 10
     for _ in range(n):
-        pl, vl = T.update_weights(opt, net, b, bucket, amp_dtype=amp, batched=batched)
+        pl, vl = T.update_weights(opt, net, b, bucket, amp_dtype=amp, batched=batched, hip_convs=hip)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print("%-44s %7.2f ms/step   p_loss %.4f v_loss %.4f" % (name, dt * 1e3, float(pl), float(vl)), flush=True)
@@ -45,8 +45,12 @@ def run(name, channels_last=False, benchmark=False, amp=None, batched=None):
 
 run("fp32 NCHW, plain loss (r02)", batched=False)
 run("fp32 NCHW, batched heads + deferred weight gradients (as shipped)")
+run("fp32 NCHW, batched, HIP bf16 convolution gradients", hip=True)
 run("fp32 NCHW, plain loss (r02), again", batched=False)
 run("fp32 NCHW, batched, again")
+run("fp32 NCHW, batched, HIP bf16 convolution gradients, again", hip=True)
+if len(sys.argv) > 3 and sys.argv[3] == "short":
+    sys.exit(0)
 run("fp32 NCHW, MIOpen find (benchmark=True)", benchmark=True)
 run("fp32 channels_last", channels_last=True)
 run("fp32 channels_last, find", channels_last=True, benchmark=True)
