@@ -446,6 +446,17 @@ int64_t mz_conv3x3_wgrad_workspace(int64_t n_boards);
 int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
                      int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* The same convolutions' forward pass and data gradient (main.py:247-252 forward, :265-266 backward), one launch per layer:
+ *     y[b][co][.] = bias[co] + sum_{ci,ky,kx} W[co][ci][ky][kx] * x[b][ci][. + (ky-1, kx-1)]      (packed_fwd)
+ *     gx[b][ci][.] =           sum_{co,ky,kx} W[co][ci][ky][kx] * g[b][co][. - (ky-1, kx-1)]      (packed_bwd, bias NULL)
+ * mz_conv3x3_pack: weight (128,128,3,3) f32 -> the two bf16 stage images the kernel streams, MZ_CONV3X3_PACKED_BYTES each
+ * (16-byte aligned); repack after every optimiser step.
+ * mz_conv3x3_forward: x, y (n,128,8,8) f32 NCHW contiguous, x != y; bias (128) f32 or NULL; relu != 0 clamps y at 0.
+ * Arithmetic: x and W rounded to bf16 (nearest even), f32 products and sums (v_mfma_f32_16x16x32_bf16), f32 output. */
+#define MZ_CONV3X3_PACKED_BYTES (40 * 4096 * 2)
+int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream);
+int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

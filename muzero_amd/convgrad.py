@@ -47,3 +47,31 @@ def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False):
     nb = (C.c_int64 * k)(*[int(x.shape[0]) for x in xs])
     L.call("mz_conv3x3_wgrad", xp, gp, nb, k, L.dptr(dw), L.dptr(db), 1 if accumulate else 0, L.dptr(ws), ws.numel(), L.current_stream())
     return dw, db
+
+
+PACKED_ELEMS = 40 * 4096   # MZ_CONV3X3_PACKED_BYTES / 2
+
+
+def pack_conv(weight, out=None):
+    """conv weight (128,128,3,3) f32 on the GPU -> (forward image, data-gradient image), bf16 (mz_conv3x3_pack)"""
+    w = weight.detach()
+    if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
+        raise L.MzError("pack_conv: need a contiguous cuda float32 (128,128,3,3) weight")
+    if out is None:
+        out = torch.empty((2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
+    L.call("mz_conv3x3_pack", L.dptr(w), L.dptr(out[0]), L.dptr(out[1]), L.current_stream())
+    return out[0], out[1]
+
+
+def conv3x3(x, packed, bias=None, relu=False, out=None):
+    """y = conv3x3(x) (+ bias) with the packed weight image (forward image: the convolution; data-gradient image applied to a
+    grad_output: the input gradient).  x (n,128,8,8) f32 NCHW (mz_conv3x3_forward)."""
+    _check(x, "conv3x3 input")
+    if packed.dtype != torch.bfloat16 or packed.numel() != PACKED_ELEMS or not packed.is_cuda or not packed.is_contiguous():
+        raise L.MzError("conv3x3: packed must be one of pack_conv's images")
+    if bias is not None and (bias.dtype != torch.float32 or tuple(bias.shape) != (128,) or not bias.is_cuda):
+        raise L.MzError("conv3x3: bias must be a cuda float32 (128,) tensor")
+    y = torch.empty_like(x) if out is None else out
+    L.call("mz_conv3x3_forward", L.dptr(packed), L.dptr(bias.detach() if bias is not None else None), L.dptr(x), L.dptr(y), int(x.shape[0]), 1 if relu else 0,
+           L.current_stream())
+    return y

@@ -298,6 +298,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     }
 
     MZ_STAMP(tw, stamp_id);
+    if (MODE == 2) return;   // the training convolution (k_conv3x3): the caller stores the accumulators; nothing touches the image
     // the next layer's bias in the accumulator layout: channels cobase + 16 i + 4 kc + 0..3
     f32x4 bn[4];
 #pragma unroll
@@ -847,7 +848,111 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
     }
 }
 
+// ---- training: ONE 3x3, 128 -> 128 convolution on fp32 NCHW tensors, through the K loop above ------------------------------
+// What update_weights' forward and backward (main.py:247-266) run for the towers' residual blocks: y = conv(x) + bias, or --
+// with the flipped/transposed pack -- the data gradient of the same convolution.  One workgroup per 8-board tile: the input is
+// rounded to bf16 into the [pos][ch] image (thread = position; 8 channels per 16-byte chunk), the weights stream through the
+// ring, and the fp32 accumulators go straight back to NCHW (lane = position, so a store instruction writes 16-cell runs).
+struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; };
+
+__global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
+    mid_prologue(lds, a.w, tid);
+    {   // input: thread = position q of the tile, 16 chunks of 8 channels
+        const int q = tid, key = act_key(q);
+        const int64_t b = board0 + (q >> 6);
+        char *row = lds + OFF_X + q * 256;
+        if (b < a.n_boards) {
+            const float *src = a.x + b * 8192 + (q & 63);
+#pragma unroll 1
+            for (int c0 = 0; c0 < 16; c0 += 4) {
+                float v[4][8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[c][k] = src[((c0 + c) * 8 + k) * 64];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    *reinterpret_cast<uint4 *>(row + (((c0 + c) ^ key) << 4)) =
+                        make_uint4(pack_bf16(v[c][0], v[c][1]), pack_bf16(v[c][2], v[c][3]), pack_bf16(v[c][4], v[c][5]), pack_bf16(v[c][6], v[c][7]));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) *reinterpret_cast<uint4 *>(row + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
+    __syncthreads();
+    const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
+    const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
+    acc16_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cobase + 16 * i + 4 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = bv;
+    }
+    const Tower none{};
+    layer_mid<2>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = posbase + 16 * j + p16;
+        const int64_t b = board0 + (q >> 6);
+        if (b < a.n_boards) {
+            float *dst = a.y + (b * 128 + cobase + 4 * kc) * 64 + (q & 63);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(16 * i + e) * 64] = a.relu ? fmaxf(acc[i][j][e], 0.0f) : acc[i][j][e];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages) land before the wave ends
+}
+
+// conv weight (128 co, 128 ci, 3, 3) f32 -> the two stage images k_conv3x3 streams: [36 + 4 stages][128 rows][4 slots][8] bf16,
+//   forward : stage (ky*3+kx)*4 + ci/32, row co, element = W[co][ci][ky][kx]
+//   backward: stage (ky*3+kx)*4 + co/32, row ci, element = W[co][ci][2-ky][2-kx]   (the data gradient as a convolution of g)
+// slot s of a row holds the 8-channel chunk s ^ {0,2,3,1}[(row >> 2) & 3]; the 4 trailing stages are zero (prefetch padding)
+__global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ wsrc, uint16_t *__restrict__ fwd, uint16_t *__restrict__ bwd) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // (stage, row, slot, e)
+    if (idx >= 40 * 4096) return;
+    const int e = idx & 7, slot = (idx >> 3) & 3, row = (idx >> 5) & 127, stage = idx >> 12;
+    uint16_t f = 0, bk = 0;
+    if (stage < 36) {
+        const int tap = stage >> 2, quarter = stage & 3, ky = tap / 3, kx = tap % 3;
+        const int ch = quarter * 32 + ((slot ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3) + e;
+        f = (uint16_t)bf16_rne(wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx]);
+        bk = (uint16_t)bf16_rne(wsrc[((ch * 128 + row) * 3 + (2 - ky)) * 3 + (2 - kx)]);
+    }
+    fwd[idx] = f;
+    bwd[idx] = bk;
+}
+
 }  // namespace
+
+extern "C" int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream) {
+    MZ_REQUIRE(w && packed_fwd && packed_bwd, "mz_conv3x3_pack: null pointer");
+    MZ_REQUIRE((((uintptr_t)packed_fwd | (uintptr_t)packed_bwd) & 15) == 0, "mz_conv3x3_pack: outputs must be 16-byte aligned");
+    hipLaunchKernelGGL(k_conv3x3_pack, dim3(40 * 4096 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t *)packed_fwd, (uint16_t *)packed_bwd);
+    MZ_LAUNCH_CHECK("k_conv3x3_pack");
+    return MZ_OK;
+}
+
+extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_conv3x3_forward: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(packed && x && y, "mz_conv3x3_forward: null pointer");
+    MZ_REQUIRE((((uintptr_t)packed | (uintptr_t)bias) & 15) == 0, "mz_conv3x3_forward: packed weights and bias must be 16-byte aligned");
+    MZ_REQUIRE(x != y, "mz_conv3x3_forward: in-place call");
+    const int64_t n_tiles = (n + TILE_BOARDS - 1) / TILE_BOARDS;
+    MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
+    const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu};
+    hipLaunchKernelGGL(k_conv3x3, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    MZ_LAUNCH_CHECK("k_conv3x3");
+    return MZ_OK;
+}
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,
                         int32_t hidden_dtype, float *value, float *policy, int64_t n, void *stream, const Route &rt = Route{nullptr, nullptr, nullptr, 1}) {

@@ -93,3 +93,32 @@ def test_training_gradients_with_hip_convolutions_match_the_fp32_step():
     print("worst per-tensor relative L2 gradient difference: %.3g" % worst)
     assert worst <= 2e-2
     assert all(torch.isfinite(v).all() for v in got.values())
+
+
+@pytest.mark.parametrize("n", [1, 8, 13, 512])
+def test_conv3x3_forward_and_data_gradient_match_fp64_on_bf16_values(n):
+    from muzero_amd.convgrad import conv3x3, pack_conv
+    g = torch.Generator(device="cuda").manual_seed(n)
+    w = _bf16_values(torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03)
+    bias = torch.randn(128, device="cuda", generator=g)
+    x = _bf16_values(torch.randn(n, 128, 8, 8, device="cuda", generator=g)).relu()
+    gy = _bf16_values(torch.randn(n, 128, 8, 8, device="cuda", generator=g))
+    pf, pb = pack_conv(w)
+    y = conv3x3(x, pf, bias)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    yr = conv3x3(x, pf, bias, relu=True)
+    assert torch.equal(yr, y.clamp_min(0))
+    gx = conv3x3(gy, pb)
+    refg = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    assert (gx.double() - refg).abs().max().item() <= 1e-5 * refg.abs().max().item()
+
+
+def test_conv3x3_on_fp32_values_is_within_bf16_rounding():
+    from muzero_amd.convgrad import conv3x3, pack_conv
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03
+    x = torch.randn(64, 128, 8, 8, device="cuda", generator=g)
+    y = conv3x3(x, pack_conv(w)[0])
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    assert (y.double() - ref).norm().item() <= 4e-3 * ref.norm().item()
