@@ -107,35 +107,58 @@ def muzero_loss(network, batch):
 # gradients with the tolerances of the plain form).
 class _ConvDeferW(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, conv, sink):
-        ctx.save_for_backward(x, conv.weight)
+    def forward(ctx, x, conv, sink, packed):
         ctx.sink = sink
+        ctx.packed = packed
+        if packed is not None:   # the HIP kernels (muzero_amd/convgrad.py): operands rounded to bf16, fp32 sums
+            from .convgrad import conv3x3
+            x = x.contiguous()
+            ctx.save_for_backward(x)
+            return conv3x3(x, packed[0], conv.bias)
+        ctx.save_for_backward(x, conv.weight)
         return torch.ops.aten.convolution(x, conv.weight, conv.bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
         g = g.contiguous()
         gx = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.packed is not None:
+            from .convgrad import conv3x3
+            x, = ctx.saved_tensors
+            if ctx.needs_input_grad[0]:
+                gx = conv3x3(g, ctx.packed[1])
+        else:
+            x, w = ctx.saved_tensors
+            if ctx.needs_input_grad[0]:
+                gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         ctx.sink.append((x, g))
-        return gx, None, None
+        return gx, None, None, None
 
 
 class DeferredWeightGrads:
     """parks the (input, grad_output) pairs of every use of a convolution during backward; flush() = one weight-gradient call
     per convolution over its uses, accumulated into .grad (views of a FlatGradBucket stay views).
-    hip=True: the 3x3, 128 -> 128 convolutions' weight and bias gradients come from mz_conv3x3_wgrad (operands rounded to bf16
-    on the matrix cores, fp32 sums, no concatenation) instead of MIOpen's fp32 kernels."""
+    hip=True: the 3x3, 128 -> 128 convolutions run on the hand-written matrix-core kernels -- forward and data gradient through
+    mz_conv3x3_forward, weight and bias gradients through mz_conv3x3_wgrad (operands rounded to bf16, fp32 sums, no
+    concatenation) -- instead of MIOpen's fp32 kernels."""
 
     def __init__(self, hip=False):
         self.sinks = {}
         self.hip = bool(hip)
+        self.packed = {}
+
+    def _is_tower_conv(self, conv, x):
+        return self.hip and conv.in_channels == 128 and conv.out_channels == 128 and x.is_cuda and x.dtype == torch.float32
 
     def conv(self, x, conv):
         sink = self.sinks.setdefault(id(conv), (conv, []))[1]
-        return _ConvDeferW.apply(x, conv, sink)
+        packed = None
+        if self._is_tower_conv(conv, x):
+            packed = self.packed.get(id(conv))
+            if packed is None:   # once per step: the weights change with every optimiser step
+                from .convgrad import pack_conv
+                packed = self.packed[id(conv)] = pack_conv(conv.weight)
+        return _ConvDeferW.apply(x, conv, sink, packed)
 
     @torch.no_grad()
     def flush(self):
@@ -143,7 +166,7 @@ class DeferredWeightGrads:
             if not sink:
                 continue
             has_b = conv.bias is not None
-            if self.hip and conv.in_channels == 128 and conv.out_channels == 128 and sink[0][0].is_cuda and sink[0][0].dtype == torch.float32:
+            if self._is_tower_conv(conv, sink[0][0]):
                 from .convgrad import conv3x3_wgrad
                 for prm in (conv.weight, conv.bias):
                     if prm is not None and prm.grad is None:

@@ -75,9 +75,22 @@ def _grads(net, batch, hip):
     return float(pl.detach()), float(vl.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
 
+def _autocast_grads(net, batch):
+    from muzero_amd import train as T
+    for p in net.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pl, vl = T.muzero_loss(net, batch)
+    (pl.float() + vl.float()).backward()
+    return {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+
 def test_training_gradients_with_hip_convolutions_match_the_fp32_step():
-    """the whole K = 5 unrolled loss: every parameter's gradient with the towers' convolution gradients from the HIP kernels
-    against the fp32 PyTorch/MIOpen step on the same weights and batch (bf16 operand rounding: per-tensor relative L2)"""
+    """the whole K = 5 unrolled loss: every parameter's gradient with the towers' convolutions (forward, data and weight
+    gradient) on the HIP kernels against the fp32 PyTorch/MIOpen step on the same weights and batch.  The difference is bf16
+    operand rounding through 36 convolutions in a row; measured on MI355X (tools/train_grad_noise.py), per-tensor relative L2:
+    B = 64: worst 5.3e-2, median 1.6e-2 (torch.autocast(bfloat16) on the same step: 7.1e-2 / 2.3e-2); B = 512: worst 3.4e-2,
+    median 6.0e-3 (autocast: 1.7e-1 / 1.1e-2).  Bounds: absolute, and not worse than PyTorch's own bf16 path."""
     from muzero_amd.network import Network
     torch.manual_seed(1261)
     net = Network().to("cuda")
@@ -88,10 +101,14 @@ def test_training_gradients_with_hip_convolutions_match_the_fp32_step():
              (torch.rand(K + 1, B, generator=g) * 2 - 1).cuda(), torch.softmax(torch.rand(K + 1, B, 65, generator=g), -1).cuda())
     pl0, vl0, ref = _grads(net, batch, hip=False)
     pl1, vl1, got = _grads(net, batch, hip=True)
+    amp = _autocast_grads(net, batch)
     assert abs(pl0 - pl1) <= 2e-3 * abs(pl0) and abs(vl0 - vl1) <= 2e-3 * abs(vl0)
-    worst = max(float((got[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-12)) for k in ref)
-    print("worst per-tensor relative L2 gradient difference: %.3g" % worst)
-    assert worst <= 2e-2
+    rel = lambda d: sorted(float((d[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-12)) for k in ref)  # noqa: E731
+    mine, theirs = rel(got), rel(amp)
+    print("per-tensor relative L2 gradient difference to fp32: HIP worst %.3g median %.3g; autocast worst %.3g median %.3g" %
+          (mine[-1], mine[len(mine) // 2], theirs[-1], theirs[len(theirs) // 2]))
+    assert mine[-1] <= 1e-1 and mine[len(mine) // 2] <= 3e-2
+    assert mine[-1] <= 1.25 * theirs[-1] and mine[len(mine) // 2] <= 1.25 * theirs[len(theirs) // 2]
     assert all(torch.isfinite(v).all() for v in got.values())
 
 

@@ -32,3 +32,14 @@ for uses, n in ((1, 512), (5, 512)):
     t_mi = timeit(miopen)
     print("wgrad %d x %d boards: hip %.1f us (%.0f TFLOP/s, %.2f TB/s of fp32 operands)   miopen (cat + wrw + bias) %.1f us" %
           (uses, n, t_hip, flop / t_hip / 1e6, uses * n * 65536 / t_hip / 1e6, t_mi), flush=True)
+
+for n in (512, 2560):
+    x = torch.randn(n, 128, 8, 8, device="cuda").relu()
+    y = torch.empty_like(x)
+    b = torch.randn(128, device="cuda")
+    pf, pb = CG.pack_conv(w)
+    flop = 2.0 * n * 64 * 128 * 128 * 9
+    t_hip = timeit(lambda: CG.conv3x3(x, pf, b, out=y))
+    t_mi = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=1))
+    print("conv %d boards: hip %.1f us (%.0f TFLOP/s)   miopen fp32 %.1f us" % (n, t_hip, flop / t_hip / 1e6, t_mi), flush=True)
+print("pack: %.1f us" % timeit(lambda: CG.pack_conv(w)))
