@@ -40,7 +40,7 @@ constexpr int RING = 3;
 constexpr int OFF_ZERO = RING * BOARD_BYTES;             // 32 bytes of zeros: the fragment of a row outside the board
 constexpr int WG_LDS = OFF_ZERO + 64;
 constexpr int DMA_PER_BOARD = BOARD_BYTES / 1024 / 8;    // 6 LDS-DMA instructions per wave per board
-constexpr int PART_FLOATS = 2 * 8 * 4 * 9 * 4 * 64;      // 147,456 = 128 x 128 x 9, in accumulator order [half][wave][ct][tap][i][lane]
+constexpr int PART_FLOATS = 2 * 8 * 4 * 9 * 4 * 64;      // 147,456 = 128 x 128 x 9, in accumulator order [half][wave][ct][tap][lane][i]
 constexpr int TARGET_SLICES = 128;
 
 struct WgradArgs {
@@ -173,13 +173,7 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float *p = part + (ct * 9 + t) * 256 + l;
-            p[0] = acc[ct][t].x;
-            p[64] = acc[ct][t].y;
-            p[128] = acc[ct][t].z;
-            p[192] = acc[ct][t].w;
-        }
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4 *>(part + (ct * 9 + t) * 256 + l * 4) = acc[ct][t];
     if (w < 4) {   // bias gradient of co tile w: add the four k-groups (board rows) of each channel
         gsum += __shfl_xor(gsum, 16);
         gsum += __shfl_xor(gsum, 32);
@@ -187,42 +181,42 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
     }
 }
 
-// dW[co][ci][ky][kx] (+)= sum over slices, in slice order; the last 128 threads do the bias gradient
+// dW[co][ci][ky][kx] (+)= sum over slices.  A block owns 64 consecutive partial elements; its four waves each add every fourth
+// slice (slices q, q + 4, ...), then the four sums are added ((0 + 1) + (2 + 3)): a fixed order, four times the loads in flight.
+// The blocks behind PART_FLOATS / 64 do the bias gradient.
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ partial, const float *__restrict__ db_partial, int slices,
                                                       float *__restrict__ dw, float *__restrict__ db, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < PART_FLOATS) {
-        // four interleaved running sums (slices 4 j + q), added ((0 + 1) + (2 + 3)): a fixed order, and four loads in flight
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int sl = 0;
-#pragma unroll 2
-        for (; sl + 4 <= slices; sl += 4) {
-            v0 += partial[(size_t)sl * PART_FLOATS + e];
-            v1 += partial[(size_t)(sl + 1) * PART_FLOATS + e];
-            v2 += partial[(size_t)(sl + 2) * PART_FLOATS + e];
-            v3 += partial[(size_t)(sl + 3) * PART_FLOATS + e];
-        }
-        for (; sl < slices; ++sl) v0 += partial[(size_t)sl * PART_FLOATS + e];
-        const float v = (v0 + v1) + (v2 + v3);
-        const int lane = e & 63, i = (e >> 6) & 3;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool bias = e >= PART_FLOATS;
+    const float *src = bias ? db_partial + (e - PART_FLOATS) : partial + e;
+    const size_t stride = bias ? 128 : PART_FLOATS;
+    float v = 0.f;
+    if (!bias || (db && e < PART_FLOATS + 128))
+        for (int sl = q; sl < slices; sl += 4) v += src[(size_t)sl * stride];
+    red[q][lane] = v;
+    __syncthreads();
+    if (q != 0) return;
+    v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (!bias) {
+        const int i = e & 3, ln = (e >> 2) & 63;
         int rest = e >> 8;
         const int tap = rest % 9;
         rest /= 9;
         const int ct = rest & 3, w = (rest >> 2) & 7, half = rest >> 5;
-        const int co = half * 64 + 16 * ct + 4 * (lane >> 4) + i, ci = 16 * w + (lane & 15);
+        const int co = half * 64 + 16 * ct + 4 * (ln >> 4) + i, ci = 16 * w + (ln & 15);
         float *o = dw + ((size_t)co * 128 + ci) * 9 + tap;
         *o = accumulate ? *o + v : v;
-    } else if (e < PART_FLOATS + 128 && db) {
+    } else if (db && e < PART_FLOATS + 128) {
         const int co = e - PART_FLOATS;
-        float v = 0.f;
-        for (int sl = 0; sl < slices; ++sl) v += db_partial[(size_t)sl * 128 + co];
         db[co] = accumulate ? db[co] + v : v;
     }
 }
 
 inline int64_t wgrad_per_slice(int64_t n_boards) {
     int64_t per = (n_boards + TARGET_SLICES - 1) / TARGET_SLICES;
-    return per < 4 ? 4 : per;
+    return per < 8 ? 8 : per;   // a slice's partial sums cost 1.2 MB of traffic: at least 8 boards of work behind them
 }
 
 }  // namespace
@@ -260,7 +254,7 @@ extern "C" int mz_conv3x3_wgrad(const float *const *x, const float *const *g, co
     a.db_partial = a.partial + slices * (int64_t)PART_FLOATS;
     hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(2 * slices)), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_conv_wgrad");
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((PART_FLOATS + 128 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a.partial, a.db_partial, (int)slices, dw,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((PART_FLOATS + 128 + 63) / 64), dim3(256), 0, (hipStream_t)stream, a.partial, a.db_partial, (int)slices, dw,
                        db, (int)accumulate);
     MZ_LAUNCH_CHECK("k_wgrad_reduce");
     return MZ_OK;

@@ -22,5 +22,5 @@ opt = T.make_optimizer(net)
 bucket = T.FlatGradBucket(net.parameters())
 net.steps = 1
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
-    T.update_weights(opt, net, b, bucket, amp_dtype=amp)
+    T.update_weights(opt, net, b, bucket, amp_dtype=amp, hip_convs=(mode == "hip"))
 torch.cuda.synchronize()
