@@ -272,6 +272,14 @@ def bench_train(args, device, rec):
         T.update_weights(opt, net, rb.sample_batch(K), bucket, amp_dtype=torch.bfloat16)
     torch.cuda.synchronize()
     dt_amp = (time.perf_counter() - t0) / iters
+    # the towers' 128 -> 128 convolutions (forward, data gradient, weight gradient) on the hand-written matrix-core kernels
+    for _ in range(3 + iters):
+        if _ == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs=True)
+    torch.cuda.synchronize()
+    dt_hip = (time.perf_counter() - t0) / iters
     config.num_unroll_steps = 3
     # arithmetic of one step: K + 1 network passes over B boards (one Representation, K Dynamics: the same tower FLOPs), each
     # forward + gradient w.r.t. its input + gradient w.r.t. its weights = 3 x the forward FLOPs (heads and loss are < 1 %)
@@ -281,8 +289,12 @@ def bench_train(args, device, rec):
             "bf16_autocast_ms_per_step": dt_amp * 1e3, "algorithmic_flop_per_step": flop,
             "tflops": flop / dt / 1e12, "frac_of_fp32_matrix_peak": flop / dt / 1e12 / F32_PEAK_TFLOPS,
             "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
-            "note": "MIOpen convolutions through PyTorch autograd (fp32 as the reference; the autocast figure keeps fp32 master weights): "
-                    "the step is kernel-bound, not launch-bound (DESIGN.md 5); hand-written bf16 backward kernels are the next-list item"}
+            "hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
+            "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
+            "note": "ms_per_step: MIOpen convolutions through PyTorch autograd, fp32 as the reference; bf16_autocast: torch.autocast over the same "
+                    "(fp32 master weights); hip_convs: the towers' 128 -> 128 convolutions -- forward, data gradient, weight gradient -- on the "
+                    "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
+                    "gradients closer to the fp32 step's than autocast's, tests/test_gpu_convgrad.py), everything else as the fp32 step"}
 
 
 def bench_loop(args, device, dtype):
@@ -310,10 +322,26 @@ def bench_loop(args, device, dtype):
     lp.generation(steps, overlap=True)
     torch.cuda.synchronize()
     dto = time.perf_counter() - t0
+    # and with the training steps' tower convolutions on the HIP kernels (train_convs="hip")
+    lp.hip_convs = True
+    lp.generation(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lp.generation(steps)
+    torch.cuda.synchronize()
+    dth = time.perf_counter() - t0
+    lp.generation(2, overlap=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lp.generation(steps, overlap=True)
+    torch.cuda.synchronize()
+    dtho = time.perf_counter() - t0
     config.num_unroll_steps = 3
     return {"games": g, "simulations": args.selfplay_sims, "train_steps": steps, "batch": args.train_batch,
             "unroll_steps": args.train_unroll, "seconds_per_generation": dt, "games_per_sec": g / dt,
             "overlapped_seconds_per_generation": dto, "overlapped_games_per_sec": g / dto,
+            "hip_convs_seconds_per_generation": dth, "hip_convs_games_per_sec": g / dth,
+            "hip_convs_overlapped_seconds_per_generation": dtho, "hip_convs_overlapped_games_per_sec": g / dtho,
             "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 
 

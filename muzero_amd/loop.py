@@ -37,11 +37,14 @@ from . import train as T
 
 class MuZeroLoop:
     def __init__(self, games_per_rank, device="cuda", infer_dtype=torch.bfloat16, num_simulations=None, window_size=None,
-                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated"):
+                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated", train_convs="fp32"):
         """replay_mode "replicated": trajectories are all_gathered and every rank holds the whole window (what
         BASELINE configs[3] describes); "sharded": no gather at all -- every rank keeps only the games it played (1/N of the
         window), all ranks make the same global draws and each trains on the draws that hit its own games, with the
-        gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw."""
+        gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw.
+        train_convs "fp32": the reference's arithmetic (PyTorch/MIOpen); "hip": the towers' 128 -> 128 convolutions and their
+        gradients on the hand-written matrix-core kernels (bf16 operands, fp32 sums and master weights: train.update_weights
+        hip_convs)."""
         self.group = group
         self.world = dist.get_world_size(group) if T._dist_on(group) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -62,6 +65,9 @@ class MuZeroLoop:
         if replay_mode not in ("replicated", "sharded"):
             raise ValueError("replay_mode must be 'replicated' or 'sharded'")
         self.replay_mode = replay_mode
+        if train_convs not in ("fp32", "hip"):
+            raise ValueError("train_convs must be 'fp32' or 'hip'")
+        self.hip_convs = train_convs == "hip"
         self.games_per_rank = int(games_per_rank)
         window = int(window_size if window_size is not None else config.window_size)
         if replay_mode == "sharded":
@@ -100,7 +106,7 @@ class MuZeroLoop:
                     if r == self.rank]
             batch = self.replay.sample_batch(K, [li for li, _ in mine], [p for _, p in mine]) if mine else None
             scale = len(mine) * self.world / self.batch_size
-        return T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group, loss_scale=scale)
+        return T.update_weights(self.optimizer, self.network, batch, self.bucket, self.group, loss_scale=scale, hip_convs=self.hip_convs)
 
     def _publish(self):
         self.storage.save_network(self.network.state_dict())

@@ -31,6 +31,30 @@ def test_two_generations():
         config.num_unroll_steps = old
 
 
+def test_generations_with_hip_training_convolutions():
+    """train_convs="hip": the same loop with the towers' convolutions and their gradients on the hand-written kernels; the
+    first generation plays the same games (same initial weights) and draws the same batches; its losses follow the fp32 loop's
+    to bf16 rounding, step by step"""
+    from muzero_amd import config
+    from muzero_amd.loop import MuZeroLoop
+    old = config.num_unroll_steps
+    config.num_unroll_steps = 5
+    try:
+        out = {}
+        for mode in ("fp32", "hip"):
+            loop = MuZeroLoop(64, num_simulations=6, window_size=64, batch_size=32, infer_dtype=torch.bfloat16, train_convs=mode)
+            out[mode] = [(float(p), float(v)) for p, v in loop.generation(6)]
+            assert loop.network.steps == 6
+            for a, b in zip(loop.infer.net.state_dict().values(), loop.network.state_dict().values()):
+                assert torch.equal(a, b.to(a.dtype))
+        a, b = np.array(out["fp32"]), np.array(out["hip"])
+        assert np.isfinite(b).all()
+        assert np.allclose(a[0], b[0], rtol=2e-3)          # same weights, same batch: forward in bf16 vs fp32
+        assert np.allclose(a, b, rtol=5e-2)                 # six SGD steps apart
+    finally:
+        config.num_unroll_steps = old
+
+
 def test_sharded_window_equals_replicated_on_one_rank():
     """replay_mode="sharded" (no trajectory gather, local batches weighted in the all-reduce) makes the same draws and the
     same updates as the replicated window; with one rank the two must agree exactly"""
