@@ -205,11 +205,13 @@ __device__ __forceinline__ void mid_prologue(char *lds, const uint4 *__restrict_
 //   D:               lane l -> col pos, rows co = 16 i + 4 (l >> 4) + 0..3       = 8 bytes of the [pos][ch] image
 typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
-template <int MODE>
-__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][8],
+// NJ = position tiles per wave: 8 (two boards per wave, the 8-board tile of the serving kernel) or 4 (one board per wave, a
+// 4-board tile: the training convolution on small batches, where twice the workgroups matter more than the K loop's density)
+template <int MODE, int NJ = 8>
+__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][NJ],
                                           const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id) {
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
-    const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
+    const int cobase = 64 * (w & 1), posbase = 16 * NJ * (w >> 1);
 
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
     int waddr[4];
@@ -264,11 +266,11 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
             const int nbuf = ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[0], b[j & 3], acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[1], b[j & 3], acc[1][j], 0, 0, 0);
                 MZ_FENCE();
-                b[(j + 3) & 3] = bfrag((j + 3) & 7);   // j <= 4: this stage's tile j + 3; j >= 5: the next stage's tile j - 5 (its addresses are set behind j = 4)
+                b[(j + 3) & 3] = bfrag((j + 3) & (NJ - 1));   // j <= 4: this stage's tile j + 3; j >= 5: the next stage's tile j - 5 (its addresses are set behind j = 4)
                 MZ_FENCE();
                 acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[2], b[j & 3], acc[2][j], 0, 0, 0);
                 acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[3], b[j & 3], acc[3][j], 0, 0, 0);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
                     }
                     MZ_FENCE();
                 }
-                if (j == 4) {   // the addresses of stage st + 1 (next channel quarter, or the next tap's first)
+                if (j == NJ - 4) {   // the addresses of stage st + 1 (next channel quarter, or the next tap's first): behind the last refill that reads stage st
                     if (((ss + 1) & 3) == 0) set_tap(ss + 1 == 12 ? T + 1 : T, ss + 1 == 12 ? 0 : (ss + 1) >> 2);
                     set_kq((ss + 1) & 3);
                     MZ_FENCE();
@@ -307,7 +309,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // epilogue: lane = position, the 4 registers of a tile = channels co0 .. co0 + 3
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = posbase + 16 * j + p16;
         char *row = lds + OFF_X + q * 256 + (kc & 1) * 8;
         const int key = act_key(q);
@@ -855,19 +857,21 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
 // ring, and the fp32 accumulators go straight back to NCHW (lane = position, so a store instruction writes 16-cell runs).
 struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; };
 
+template <int NJ>   // boards per workgroup: 8 (NJ = 8) or 4 (NJ = 4: twice the workgroups for small batches)
 __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    constexpr int BOARDS = NJ, POS = 64 * NJ, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
     const int tid = threadIdx.x;
-    const int64_t board0 = (int64_t)blockIdx.x * TILE_BOARDS;
+    const int64_t board0 = (int64_t)blockIdx.x * BOARDS;
     mid_prologue(lds, a.w, tid);
-    {   // input: thread = position q of the tile, 16 chunks of 8 channels
-        const int q = tid, key = act_key(q);
+    {   // input: thread = position q of the tile, CHUNKS chunks of 8 channels
+        const int q = tid % POS, cbase = (tid / POS) * CHUNKS, key = act_key(q);
         const int64_t b = board0 + (q >> 6);
         char *row = lds + OFF_X + q * 256;
         if (b < a.n_boards) {
-            const float *src = a.x + b * 8192 + (q & 63);
+            const float *src = a.x + b * 8192 + cbase * 512 + (q & 63);
 #pragma unroll 1
-            for (int c0 = 0; c0 < 16; c0 += 4) {
+            for (int c0 = 0; c0 < CHUNKS; c0 += 4) {
                 float v[4][8];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -875,29 +879,29 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
                     for (int k = 0; k < 8; ++k) v[c][k] = src[((c0 + c) * 8 + k) * 64];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<uint4 *>(row + (((c0 + c) ^ key) << 4)) =
+                    *reinterpret_cast<uint4 *>(row + (((cbase + c0 + c) ^ key) << 4)) =
                         make_uint4(pack_bf16(v[c][0], v[c][1]), pack_bf16(v[c][2], v[c][3]), pack_bf16(v[c][4], v[c][5]), pack_bf16(v[c][6], v[c][7]));
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) *reinterpret_cast<uint4 *>(row + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            for (int c = 0; c < CHUNKS; ++c) *reinterpret_cast<uint4 *>(row + ((cbase + c) << 4)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
     __syncthreads();
     const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
-    const int cobase = 64 * (w & 1), posbase = 128 * (w >> 1);
-    acc16_t acc[4][8];
+    const int cobase = 64 * (w & 1), posbase = 16 * NJ * (w >> 1);
+    acc16_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cobase + 16 * i + 4 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = bv;
+        for (int j = 0; j < NJ; ++j) acc[i][j] = bv;
     }
     const Tower none{};
-    layer_mid<2>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
+    layer_mid<2, NJ>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int q = posbase + 16 * j + p16;
         const int64_t b = board0 + (q >> 6);
         if (b < a.n_boards) {
@@ -946,10 +950,16 @@ extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const f
     MZ_REQUIRE(packed && x && y, "mz_conv3x3_forward: null pointer");
     MZ_REQUIRE((((uintptr_t)packed | (uintptr_t)bias) & 15) == 0, "mz_conv3x3_forward: packed weights and bias must be 16-byte aligned");
     MZ_REQUIRE(x != y, "mz_conv3x3_forward: in-place call");
-    const int64_t n_tiles = (n + TILE_BOARDS - 1) / TILE_BOARDS;
+    // 8-board tiles once they fill the chip; below that 4-board tiles: twice the workgroups on a less dense K loop
+    int dev = 0, cus = 0;
+    MZ_HIP(hipGetDevice(&dev));
+    MZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const bool small = (n + 7) / 8 < cus;
+    const int64_t n_tiles = small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
     const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu};
-    hipLaunchKernelGGL(k_conv3x3, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    if (small) hipLaunchKernelGGL(k_conv3x3<4>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_conv3x3<8>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_conv3x3");
     return MZ_OK;
 }
