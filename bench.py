@@ -280,6 +280,15 @@ def bench_train(args, device, rec):
         T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs=True)
     torch.cuda.synchronize()
     dt_hip = (time.perf_counter() - t0) / iters
+    # ... and that step replayed as one hipGraph (train.GraphedUpdate): the eager step is bound by the host's launches
+    gu = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs=True)
+    for _ in range(3 + iters):
+        if _ == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        gu(rb.sample_batch(K))
+    torch.cuda.synchronize()
+    dt_hipg = (time.perf_counter() - t0) / iters
     config.num_unroll_steps = 3
     # arithmetic of one step: K + 1 network passes over B boards (one Representation, K Dynamics: the same tower FLOPs), each
     # forward + gradient w.r.t. its input + gradient w.r.t. its weights = 3 x the forward FLOPs (heads and loss are < 1 %)
@@ -291,6 +300,7 @@ def bench_train(args, device, rec):
             "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
             "hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
             "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
+            "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
             "note": "ms_per_step: MIOpen convolutions through PyTorch autograd, fp32 as the reference; bf16_autocast: torch.autocast over the same "
                     "(fp32 master weights); hip_convs: the towers' 128 -> 128 convolutions -- forward, data gradient, weight gradient -- on the "
                     "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
@@ -324,6 +334,7 @@ def bench_loop(args, device, dtype):
     dto = time.perf_counter() - t0
     # and with the training steps' tower convolutions on the HIP kernels (train_convs="hip")
     lp.hip_convs = True
+    lp.train_graph = True                 # the training step replayed as one hipGraph (train.GraphedUpdate)
     lp.generation(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -340,7 +351,7 @@ def bench_loop(args, device, dtype):
     return {"games": g, "simulations": args.selfplay_sims, "train_steps": steps, "batch": args.train_batch,
             "unroll_steps": args.train_unroll, "seconds_per_generation": dt, "games_per_sec": g / dt,
             "overlapped_seconds_per_generation": dto, "overlapped_games_per_sec": g / dto,
-            "hip_convs_seconds_per_generation": dth, "hip_convs_games_per_sec": g / dth,
+            "hip_convs_note": "train_convs=hip, train_graph=True", "hip_convs_seconds_per_generation": dth, "hip_convs_games_per_sec": g / dth,
             "hip_convs_overlapped_seconds_per_generation": dtho, "hip_convs_overlapped_games_per_sec": g / dtho,
             "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 

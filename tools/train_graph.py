@@ -20,7 +20,7 @@ def batch(seed):
             (torch.rand(K + 1, B, generator=g) * 2 - 1).to(dev), torch.softmax(torch.rand(K + 1, B, 65, generator=g), -1).to(dev))
 
 
-def run(name, benchmark, amp, graph):
+def run(name, benchmark, amp, graph, hip=False):
     torch.backends.cudnn.benchmark = benchmark
     torch.manual_seed(1261)
     net = Network().to(dev)
@@ -33,20 +33,20 @@ def run(name, benchmark, amp, graph):
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(4):
-            T.update_weights(opt, net, static, bucket, amp_dtype=amp)
+            T.update_weights(opt, net, static, bucket, amp_dtype=amp, hip_convs=hip)
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     if graph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            out = T.update_weights(opt, net, static, bucket, amp_dtype=amp)
+            out = T.update_weights(opt, net, static, bucket, amp_dtype=amp, hip_convs=hip)
         step = g.replay
     else:
         out = None
 
         def step():
             nonlocal out
-            out = T.update_weights(opt, net, static, bucket, amp_dtype=amp)
+            out = T.update_weights(opt, net, static, bucket, amp_dtype=amp, hip_convs=hip)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -68,6 +68,10 @@ def run(name, benchmark, amp, graph):
           (name, dt2 * 1e3, dt * 1e3, float(out[0]), float(out[1])), flush=True)
 
 
+for graph in (False, True):
+    run("fp32 + HIP bf16 tower convolutions, %s" % ("hipGraph" if graph else "eager"), False, None, graph, hip=True)
+if len(sys.argv) > 3 and sys.argv[3] == "hip":
+    sys.exit(0)
 for amp in (None, torch.bfloat16):
     for bench in (False, True):
         for graph in (False, True):
