@@ -456,6 +456,14 @@ int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t
 #define MZ_CONV3X3_PACKED_BYTES (40 * 4096 * 2)
 int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream);
 int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream);
+/* mz_conv3x3_forward with the residual block's elementwise work fused into the store phase (all tensors (n,128,8,8) f32 NCHW,
+ * skip / mask nullable, neither may alias y):   y = [relu]( [mask > 0 ?] (conv(x) + bias [+ skip]) : 0 )
+ *   forward : t = relu(conv1(h))             -> relu = 1
+ *             y = relu(h + conv2(t))         -> skip = h, relu = 1                                   (network.py:35-47)
+ *   backward: g_t   = dgrad2(g_pre) * (t > 0)                 -> mask = t
+ *             g_pre' = (g_pre + dgrad1(g_t)) * (y_prev > 0)   -> skip = g_pre, mask = y_prev  (the previous block's gate) */
+int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, const float *skip, const float *mask, float *y, int64_t n,
+                     int32_t relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -63,15 +63,20 @@ def pack_conv(weight, out=None):
     return out[0], out[1]
 
 
-def conv3x3(x, packed, bias=None, relu=False, out=None):
-    """y = conv3x3(x) (+ bias) with the packed weight image (forward image: the convolution; data-gradient image applied to a
-    grad_output: the input gradient).  x (n,128,8,8) f32 NCHW (mz_conv3x3_forward)."""
+def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None):
+    """y = [relu]( [mask > 0 ?] (conv3x3(x) + bias [+ skip]) : 0 ) with the packed weight image (forward image: the convolution;
+    data-gradient image applied to a grad_output: the input gradient).  x, skip, mask (n,128,8,8) f32 NCHW (mz_conv3x3_fused)."""
     _check(x, "conv3x3 input")
+    for t, name in ((skip, "skip"), (mask, "mask")):
+        if t is not None:
+            _check(t, "conv3x3 " + name)
+            if t.shape != x.shape:
+                raise L.MzError("conv3x3: %s has another batch size" % name)
     if packed.dtype != torch.bfloat16 or packed.numel() != PACKED_ELEMS or not packed.is_cuda or not packed.is_contiguous():
         raise L.MzError("conv3x3: packed must be one of pack_conv's images")
     if bias is not None and (bias.dtype != torch.float32 or tuple(bias.shape) != (128,) or not bias.is_cuda):
         raise L.MzError("conv3x3: bias must be a cuda float32 (128,) tensor")
     y = torch.empty_like(x) if out is None else out
-    L.call("mz_conv3x3_forward", L.dptr(packed), L.dptr(bias.detach() if bias is not None else None), L.dptr(x), L.dptr(y), int(x.shape[0]), 1 if relu else 0,
-           L.current_stream())
+    L.call("mz_conv3x3_fused", L.dptr(packed), L.dptr(bias.detach() if bias is not None else None), L.dptr(x), L.dptr(skip), L.dptr(mask), L.dptr(y),
+           int(x.shape[0]), 1 if relu else 0, L.current_stream())
     return y

@@ -855,9 +855,12 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
 // with the flipped/transposed pack -- the data gradient of the same convolution.  One workgroup per 8-board tile: the input is
 // rounded to bf16 into the [pos][ch] image (thread = position; 8 channels per 16-byte chunk), the weights stream through the
 // ring, and the fp32 accumulators go straight back to NCHW (lane = position, so a store instruction writes 16-cell runs).
-struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; };
+struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; const float *skip; const float *mask; };
 
-template <int NJ>   // boards per workgroup: 8 (NJ = 8) or 4 (NJ = 4: twice the workgroups for small batches)
+// Epilogue (EPI bit 0: skip, bit 1: mask), all on (n,128,8,8) f32 NCHW tensors: y = [relu]( [mask > 0 ?] (acc [+ skip]) : 0 ).
+// That is the residual block's forward tail relu(h + conv(t)) and, in the backward pass, the ReLU gates and the skip path's
+// gradient: g_t = dgrad(g_pre) * (t > 0);  g_pre_prev = (g_pre + dgrad(g_t)) * (y_prev > 0) -- no elementwise pass of their own.
+template <int NJ, int EPI>   // NJ boards per workgroup: 8, or 4 (twice the workgroups for small batches)
 __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     constexpr int BOARDS = NJ, POS = 64 * NJ, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
@@ -905,11 +908,29 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
         const int q = posbase + 16 * j + p16;
         const int64_t b = board0 + (q >> 6);
         if (b < a.n_boards) {
-            float *dst = a.y + (b * 128 + cobase + 4 * kc) * 64 + (q & 63);
+            const int64_t o = (b * 128 + cobase + 4 * kc) * 64 + (q & 63);
+            float sk[4][4], mk[4][4];
+            if (EPI & 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sk[i][e] = a.skip[o + (16 * i + e) * 64];
+            }
+            if (EPI & 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mk[i][e] = a.mask[o + (16 * i + e) * 64];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[(16 * i + e) * 64] = a.relu ? fmaxf(acc[i][j][e], 0.0f) : acc[i][j][e];
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][e];
+                    if (EPI & 1) v += sk[i][e];
+                    if (EPI & 2) v = mk[i][e] > 0.0f ? v : 0.0f;
+                    a.y[o + (16 * i + e) * 64] = a.relu ? fmaxf(v, 0.0f) : v;
+                }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages) land before the wave ends
@@ -944,7 +965,8 @@ extern "C" int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bw
     return MZ_OK;
 }
 
-extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream) {
+extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, const float *skip, const float *mask, float *y, int64_t n,
+                               int32_t relu, void *stream) {
     MZ_REQUIRE(n >= 0, "mz_conv3x3_forward: n < 0");
     if (n == 0) return MZ_OK;
     MZ_REQUIRE(packed && x && y, "mz_conv3x3_forward: null pointer");
@@ -957,11 +979,26 @@ extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const f
     const bool small = (n + 7) / 8 < cus;
     const int64_t n_tiles = small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
-    const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu};
-    if (small) hipLaunchKernelGGL(k_conv3x3<4>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_conv3x3<8>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    MZ_REQUIRE(skip != y && mask != y, "mz_conv3x3_fused: skip / mask alias the output");
+    const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu, skip, mask};
+    const dim3 grid((unsigned)n_tiles), block(512);
+    const hipStream_t st = (hipStream_t)stream;
+    switch ((small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
+        case 0: hipLaunchKernelGGL((k_conv3x3<8, 0>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_conv3x3<8, 1>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_conv3x3<8, 2>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((k_conv3x3<8, 3>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((k_conv3x3<4, 0>), grid, block, 0, st, a); break;
+        case 5: hipLaunchKernelGGL((k_conv3x3<4, 1>), grid, block, 0, st, a); break;
+        case 6: hipLaunchKernelGGL((k_conv3x3<4, 2>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((k_conv3x3<4, 3>), grid, block, 0, st, a); break;
+    }
     MZ_LAUNCH_CHECK("k_conv3x3");
     return MZ_OK;
+}
+
+extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream) {
+    return mz_conv3x3_fused(packed, bias, x, nullptr, nullptr, y, n, relu, stream);
 }
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,

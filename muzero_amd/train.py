@@ -150,15 +150,19 @@ class DeferredWeightGrads:
     def _is_tower_conv(self, conv, x):
         return self.hip and conv.in_channels == 128 and conv.out_channels == 128 and x.is_cuda and x.dtype == torch.float32
 
+    def pack(self, conv):
+        packed = self.packed.get(id(conv))
+        if packed is None:   # once per step: the weights change with every optimiser step
+            from .convgrad import pack_conv
+            packed = self.packed[id(conv)] = pack_conv(conv.weight)
+        return packed
+
+    def park(self, conv, x, g):
+        self.sinks.setdefault(id(conv), (conv, []))[1].append((x, g))
+
     def conv(self, x, conv):
         sink = self.sinks.setdefault(id(conv), (conv, []))[1]
-        packed = None
-        if self._is_tower_conv(conv, x):
-            packed = self.packed.get(id(conv))
-            if packed is None:   # once per step: the weights change with every optimiser step
-                from .convgrad import pack_conv
-                packed = self.packed[id(conv)] = pack_conv(conv.weight)
-        return _ConvDeferW.apply(x, conv, sink, packed)
+        return _ConvDeferW.apply(x, conv, sink, self.pack(conv) if self._is_tower_conv(conv, x) else None)
 
     @torch.no_grad()
     def flush(self):
@@ -188,7 +192,49 @@ class DeferredWeightGrads:
             sink.clear()
 
 
+class _TowerHip(torch.autograd.Function):
+    """a tower's residual blocks relu(x + conv(relu(conv(x)))) (network.py:35-47) on the HIP kernels with every elementwise
+    operation in a convolution's store phase (mz_conv3x3_fused): forward  t = relu(conv1(y)), y' = relu(y + conv2(t));
+    backward  g_t = dgrad2(g_pre) * (t > 0),  g_pre' = (g_pre + dgrad1(g_t)) * (y_prev > 0)  -- the skip path's gradient and the
+    previous block's ReLU gate in one epilogue.  Weight gradients are parked in dw as for _ConvDeferW."""
+
+    @staticmethod
+    def forward(ctx, h0, blocks, dw):
+        from .convgrad import conv3x3
+        y = h0.contiguous()
+        saved, packs = [y], []
+        for blk in blocks:
+            c1, c2 = blk.block[0], blk.block[2]
+            p1, p2 = dw.pack(c1), dw.pack(c2)
+            t = conv3x3(y, p1[0], c1.bias, relu=True)
+            y = conv3x3(t, p2[0], c2.bias, relu=True, skip=y)
+            saved += [t, y]
+            packs.append((p1, p2))
+        ctx.save_for_backward(*saved)
+        ctx.blocks, ctx.dw, ctx.packs = blocks, dw, packs
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from .convgrad import conv3x3
+        saved = ctx.saved_tensors                                  # h0, t1, y1, t2, y2, t3, y3
+        g_pre = torch.ops.aten.threshold_backward(g.contiguous(), saved[-1], 0)   # the last block's ReLU gate
+        for k in range(len(ctx.blocks) - 1, -1, -1):
+            c1, c2 = ctx.blocks[k].block[0], ctx.blocks[k].block[2]
+            p1, p2 = ctx.packs[k]
+            y_prev, t = saved[2 * k], saved[2 * k + 1]
+            g_t = conv3x3(g_pre, p2[1], mask=t)
+            ctx.dw.park(c2, t, g_pre)
+            g_prev = conv3x3(g_t, p1[1], skip=g_pre, mask=y_prev if k > 0 else None)   # h0's own gate belongs to the caller's ReLU
+            ctx.dw.park(c1, y_prev, g_t)
+            g_pre = g_prev
+        return g_pre, None, None
+
+
 def _tower_deferred(blocks, h, dw):
+    blocks = tuple(blocks)
+    if dw.hip and h.requires_grad and all(dw._is_tower_conv(c, h) for blk in blocks for c in (blk.block[0], blk.block[2])):
+        return _TowerHip.apply(h, blocks, dw)
     for blk in blocks:
         t = torch.relu(dw.conv(h, blk.block[0]))
         h = torch.relu(h + dw.conv(t, blk.block[2]))

@@ -178,3 +178,19 @@ def test_graphed_update_equals_eager_steps(hip):
     # bit-reproducible) can flip a rounding, so the bound is on the update, not on the bits
     for a, b, w0 in zip(runs[0][1], runs[1][1], runs[0][2]):
         assert (a - b).norm().item() <= 2e-2 * (a - w0).norm().item() + 1e-9
+
+
+@pytest.mark.parametrize("n", [5, 2051])
+def test_conv3x3_fused_epilogues(n):
+    """skip / mask / relu in the store phase == the same elementwise operations applied to the plain kernel's output"""
+    from muzero_amd.convgrad import conv3x3, pack_conv
+    g = torch.Generator(device="cuda").manual_seed(n + 1)
+    w = torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03
+    bias = torch.randn(128, device="cuda", generator=g)
+    x, skip, mask = (torch.randn(n, 128, 8, 8, device="cuda", generator=g) for _ in range(3))
+    mask = mask.relu()   # a post-ReLU activation: zeros and positives
+    pf, _ = pack_conv(w)
+    y = conv3x3(x, pf, bias)
+    assert torch.equal(conv3x3(x, pf, bias, relu=True, skip=skip), (y + skip).clamp_min(0))
+    assert torch.equal(conv3x3(x, pf, bias, mask=mask), torch.where(mask > 0, y, torch.zeros_like(y)))
+    assert torch.equal(conv3x3(x, pf, bias, skip=skip, mask=mask), torch.where(mask > 0, y + skip, torch.zeros_like(y)))
