@@ -289,6 +289,25 @@ def bench_train(args, device, rec):
         gu(rb.sample_batch(K))
     torch.cuda.synchronize()
     dt_hipg = (time.perf_counter() - t0) / iters
+    # the two hand-written training kernels alone, at the step's own sizes (HIP events over 30 launches each, torch's current
+    # stream = the stream they are launched on): one convolution of one use (B boards), one weight gradient over the K uses
+    from muzero_amd import convgrad as CG
+    gen = torch.Generator(device=device).manual_seed(7)
+    wconv = torch.randn(128, 128, 3, 3, device=device, generator=gen) * 0.03
+    xs = [torch.randn(B, 128, 8, 8, device=device, generator=gen).relu() for _ in range(K)]
+    gs = [torch.randn(B, 128, 8, 8, device=device, generator=gen) for _ in range(K)]
+    pf, _pb = CG.pack_conv(wconv)
+    yb, dwb, dbb = torch.empty_like(xs[0]), torch.empty_like(wconv), torch.empty(128, device=device)
+    us_conv = event_time_ms(lambda: CG.conv3x3(xs[0], pf, out=yb), 30) * 1e3
+    us_wgrad = event_time_ms(lambda: CG.conv3x3_wgrad(xs, gs, dwb, dbb), 30) * 1e3
+    conv_flop = 2.0 * B * 64 * 128 * 128 * 9
+    hip_kernels = {
+        "k_conv3x3": {"boards": B, "us_per_launch": us_conv, "tflops": conv_flop / us_conv / 1e6, "frac_of_bf16_peak": conv_flop / us_conv / 1e6 / BF16_PEAK_TFLOPS,
+                      "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board)"},
+        "k_conv_wgrad+k_wgrad_reduce": {"boards": B * K, "us_per_launch": us_wgrad, "tflops": K * conv_flop / us_wgrad / 1e6,
+                                        "frac_of_bf16_peak": K * conv_flop / us_wgrad / 1e6 / BF16_PEAK_TFLOPS,
+                                        "note": "weight + bias gradient over the K uses, fp32 NCHW operands by LDS-DMA, slice partial sums reduced in a fixed order"}}
+    del xs, gs
     config.num_unroll_steps = 3
     # arithmetic of one step: K + 1 network passes over B boards (one Representation, K Dynamics: the same tower FLOPs), each
     # forward + gradient w.r.t. its input + gradient w.r.t. its weights = 3 x the forward FLOPs (heads and loss are < 1 %)
@@ -300,7 +319,7 @@ def bench_train(args, device, rec):
             "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
             "hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
             "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
-            "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
+            "hip_kernels": hip_kernels, "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
             "note": "ms_per_step: MIOpen convolutions through PyTorch autograd, fp32 as the reference; bf16_autocast: torch.autocast over the same "
                     "(fp32 master weights); hip_convs: the towers' 128 -> 128 convolutions -- forward, data gradient, weight gradient -- on the "
                     "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
