@@ -29,9 +29,8 @@ timeout -k 10 200 python3 tools/tower_stamps.py 4096 2>&1 | grep -v amdgpu.ids >
 timeout -k 10 200 python3 tools/tower_bench.py 4096 2>&1 | grep -v amdgpu.ids > $O/tower_vs_miopen.txt || exit 1
 step bench
 step training step kernel stats
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tstats -o t -- python3 tools/train_prof.py hip 12 > $O/train_prof.out 2> $O/tstats.err || exit 1
-cp $(find $O/tstats -name "t_kernel_stats.csv" | head -1) $O/train_hip_kernel_stats.csv || exit 1
+bash tools/train_gaps.sh hip > $O/train_hip_step_kernels.txt 2>&1 || exit 1   # steady-state window of the kernel trace: busy time per kernel
 timeout -k 10 120 python3 tools/convgrad_bench.py 2>&1 | grep -v amdgpu.ids > $O/train_kernels_vs_miopen.txt || exit 1
 timeout -k 10 600 python3 bench.py > $O/bench_final.json 2> $O/bench_final.err || exit 1
-rm -rf $O/stats $O/pmc_f $O/pmc_w $O/sq $O/tstats
+rm -rf $O/stats $O/pmc_f $O/pmc_w $O/sq
 echo done
