@@ -85,12 +85,15 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
     const kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     const int tid = threadIdx.x, l = tid & 63, r = l & 15, kg = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = blockIdx.x & 1, slice = blockIdx.x >> 1;
+    // workgroups b and b + 8 run on the same XCD (round-robin dispatch): a slice's two co halves sit there, so the 32 KB of input
+    // planes they both read per board cross HBM once and are shared through that XCD's L2
+    const int half = (blockIdx.x >> 3) & 1, slice = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7);
     const int n_seg = karg<int>(ka, offsetof(WgradArgs, n_seg));
     const int per_slice = karg<int>(ka, offsetof(WgradArgs, per_slice));
     const long long n_all = karg<long long>(ka, offsetof(WgradArgs, start) + 8 * (size_t)n_seg);
-    const long long b0 = (long long)slice * per_slice;
+    const long long b0 = (long long)slice * per_slice;   // a slice index at or past the real count (grid rounded up to 16) has b0 >= n_all
     const long long b1 = b0 + per_slice < n_all ? b0 + per_slice : n_all;
+    if (b0 >= n_all) return;   // the whole workgroup: a padding slice of the rounded-up grid owns no partial sums
 
     if (tid < 16) reinterpret_cast<float *>(lds + OFF_ZERO)[tid] = 0.f;
     __syncthreads();
@@ -252,7 +255,7 @@ extern "C" int mz_conv3x3_wgrad(const float *const *x, const float *const *g, co
     a.per_slice = (int)per;
     a.partial = (float *)workspace;
     a.db_partial = a.partial + slices * (int64_t)PART_FLOATS;
-    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(2 * slices)), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(16 * ((slices + 7) / 8))), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_conv_wgrad");
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((PART_FLOATS + 128 + 63) / 64), dim3(256), 0, (hipStream_t)stream, a.partial, a.db_partial, (int)slices, dw,
                        db, (int)accumulate);
