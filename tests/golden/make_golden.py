@@ -3,6 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk [n_games]    (verdict only, ~25 min on 8 cores)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows]    (verdicts only)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -838,10 +839,129 @@ def gen_bulk_mcts(n_searches=10240):
     assert tot["mismatches"] == 0
 
 
+# ------------------------------------------------------------------------------------------------
+# bulk verdict for the REPLAY BUFFER (utilities.py:46-109, reversi.py:301-341): reference sample_batch vs the oracle, verdict only
+# ------------------------------------------------------------------------------------------------
+class _FakeChild:
+    def __init__(self, n):
+        self.visit_count = n
+
+
+class _FakeRoot:
+    """what Game.store_search_statistics reads of a searched root (reversi.py:292-299): children's visit counts and value()"""
+
+    def __init__(self, children, value):
+        self.children, self._v = children, value
+
+    def value(self):
+        return self._v
+
+
+def _bulk_replay_chunk(args):
+    """one window: `n_games` reference Games of random legal moves (voluntary passes included) with random visit counts and
+    root values, pushed through a reference ReplayBuffer smaller than n_games (FIFO eviction), then reference sample_batch
+    calls for K = 1, 3, 5 under recorded `random` draws, each compared bit for bit with the oracle's replay_batch"""
+    import random
+    import utilities as U
+    from oracle import mz_oracle as O
+    job, n_games, window, batch, n_batches = args
+    rng = np.random.default_rng(977 + job)
+    U.config.window_size, U.config.batch_size = window, batch
+    rb = U.ReplayBuffer()
+    recs = []
+    for gi in range(n_games):
+        max_moves = int(rng.choice([60, 60, 60, 9, 14, 23, 37, 59]))
+        S = int(rng.choice([1, 6, 50, 100, 255, 800]))
+        g = M.Game()
+        visits = np.full((60, 65), -1, np.int32)
+        while not g.terminal() and len(g.action_history) < max_moves:
+            legal = sorted(g.legal_actions(), key=lambda a: a.index)
+            counts = rng.multinomial(S, rng.dirichlet(np.ones(len(legal)) * 0.5))      # sums to S; zeros allowed (an unvisited child)
+            t = len(g.action_history)
+            for a, c in zip(legal, counts):
+                visits[t, a.index] = int(c)
+            g.store_search_statistics(_FakeRoot({a.index: _FakeChild(int(c)) for a, c in zip(legal, counts)}, float(rng.uniform(-1, 1))))   # children are keyed by action index (main.py:165-175)
+            g.apply(legal[int(rng.integers(len(legal)))])
+        L = len(g.action_history)
+        hw, hb = np.zeros(61, np.uint64), np.zeros(61, np.uint64)
+        for t, obs in enumerate(g.state_history):
+            hw[t], hb[t] = _obs_bits(obs)
+        acts, rew = np.zeros(60, np.uint8), np.zeros(60, np.int8)
+        acts[:L] = [a.index for a in g.action_history]
+        rew[:L] = g.rewards
+        recs.append(dict(hist_white=hw, hist_black=hb, actions=acts, rewards=rew, visits=visits, length=L))
+        rb.save_game(g)
+    win = recs[-window:]                                   # the FIFO the reference keeps (utilities.py:56-63), oldest first
+    assert rb.buffer_size == len(win) == window
+    st = dict(samples=0, batches=0, mismatched_images=0, mismatched_actions=0, mismatched_target_values=0, mismatched_target_policies=0,
+              short_games=sum(r["length"] < 60 for r in win), samples_reaching_past_the_end=0, games_with_pass=sum(int((r["actions"][:r["length"]] == 64).any()) for r in win))
+    orig_sample, orig_randint = random.sample, random.randint
+    for bi in range(n_batches):
+        K = (1, 3, 5)[bi % 3]
+        U.config.num_unroll_steps = K
+        random.seed(1000 * job + bi)
+        idxes, poss = [], []
+
+        def rec_sample(pop, k):
+            r = orig_sample(pop, k)
+            idxes.extend(r)
+            return r
+
+        def rec_randint(a, b):
+            r = orig_randint(a, b)
+            poss.append(r)
+            return r
+
+        random.sample, random.randint = rec_sample, rec_randint
+        try:
+            img, act, tv, tp = rb.sample_batch(K)
+        finally:
+            random.sample, random.randint = orig_sample, orig_randint
+        img, act, tv, tp = (torch.FloatTensor(x).numpy() for x in (img, act, tv, tp))      # what update_weights feeds the network (main.py:236)
+        oi, oa, otv, otp = O.replay_batch(win, list(zip(idxes, poss)), K)
+        st["batches"] += 1
+        st["samples"] += batch
+        st["mismatched_images"] += int((oi != img).reshape(batch, -1).any(1).sum())
+        st["mismatched_actions"] += int((oa != act).any((0, 2, 3, 4)).sum())
+        st["mismatched_target_values"] += int((otv.view(np.uint32) != tv.view(np.uint32)).any(0).sum())
+        st["mismatched_target_policies"] += int((otp.view(np.uint32) != tp.view(np.uint32)).any((0, 2)).sum())
+        st["samples_reaching_past_the_end"] += sum(int(p + K >= win[i]["length"]) for i, p in zip(idxes, poss))
+    U.config.num_unroll_steps = 3
+    return st
+
+
+def gen_bulk_replay(n_windows=64, n_games=40, window=32, batch=16, n_batches=24):
+    """SURVEY 8(f) row 1 at bulk: n_windows x n_batches reference sample_batch calls (utilities.py:72-99 -> Game.make_image /
+    make_target, reversi.py:301-341) against oracle/mz_oracle.c's replay_batch, bit for bit on all four outputs.  Only the
+    verdict is written: tests/golden/bulk_replay_verdict.json."""
+    import json
+    import multiprocessing as mp
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    t0 = time.time()
+    tot = {}
+    with mp.Pool(8) as pool:
+        for st in pool.imap_unordered(_bulk_replay_chunk, [(j, n_games, window, batch, n_batches) for j in range(n_windows)]):
+            for k, v in st.items():
+                tot[k] = tot.get(k, 0) + int(v)
+    tot.update(windows=n_windows, games_per_window=n_games, window_size=window, batch_size=batch, unroll_steps=[1, 3, 5],
+               seconds=round(time.time() - t0, 1), processes=8,
+               reference="/root/reference utilities.ReplayBuffer.save_game / sample_batch, reversi.Game.make_image / make_target, imported in the build container",
+               compared="image, action planes, target values, target policies of every sample vs oracle/mz_oracle.c (float32 bit patterns)")
+    tot["mismatches"] = tot["mismatched_images"] + tot["mismatched_actions"] + tot["mismatched_target_values"] + tot["mismatched_target_policies"]
+    with open(os.path.join(HERE, "bulk_replay_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["mismatches"] == 0
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "bulk":
         gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
+    if what == "bulk_replay":
+        gen_bulk_replay(int(sys.argv[2]) if len(sys.argv) > 2 else 64)
         sys.exit(0)
     if what == "bulk_mcts":
         gen_bulk_mcts(int(sys.argv[2]) if len(sys.argv) > 2 else 10240)

@@ -57,3 +57,16 @@ def test_make_target_matches_selfplay_fixture():
                 _, _, tv, tp = O.replay_sample(hw, hw, S["actions_%d" % g], rew, np.pad(visits, ((0, 60 - n), (0, 0))), n, si, K)
                 assert (tv == want_v[:K + 1].astype(np.float32)).all()
                 assert (tp == want_p[:K + 1].astype(np.float32)).all()
+
+
+def test_bulk_reference_verdict_is_committed_and_clean():
+    """SURVEY 8(f) row 1 at bulk: >= 100k samples drawn by the IMPORTED reference's ReplayBuffer.sample_batch
+    (tests/golden/make_golden.py bulk_replay, build container only: random games with voluntary passes, 9..60 moves, visit counts
+    of 1..800 simulations with unvisited children, FIFO eviction, K = 1 / 3 / 5) against this oracle, float32 bit patterns of all
+    four outputs; only the verdict travels."""
+    import json
+    v = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bulk_replay_verdict.json")))
+    assert v["samples"] >= 100_000 and v["samples"] == v["batches"] * v["batch_size"]
+    assert v["mismatches"] == v["mismatched_images"] == v["mismatched_actions"] == v["mismatched_target_values"] == v["mismatched_target_policies"] == 0
+    assert v["short_games"] > 1000 and v["samples_reaching_past_the_end"] > 1000 and v["games_with_pass"] > 1000
+    assert v["games_per_window"] > v["window_size"]   # eviction happened in every window
