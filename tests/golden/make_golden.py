@@ -3,7 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk [n_games]    (verdict only, ~25 min on 8 cores)
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows]    (verdicts only)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows] | bulk_arena [n_games] | bulk_train [n_runs]    (verdicts only)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -955,10 +955,173 @@ def gen_bulk_replay(n_windows=64, n_games=40, window=32, batch=16, n_batches=24)
     assert tot["mismatches"] == 0
 
 
+# ------------------------------------------------------------------------------------------------
+# bulk verdict for the ARENA (test.py): whole reference arena games vs the oracle, verdict only
+# ------------------------------------------------------------------------------------------------
+def _ref_arena_game(mb, mw, seed):
+    """one game of the reference's arena loop (test.py:51-63) between two HashNet Controllers, with the interventions of
+    gen_arena (legal list sorted by index, loop bounded at 60 steps); returns (actions, recorded uniforms, white, black)"""
+    import test as RT
+    orig_choice = np.random.choice
+    np.random.seed(seed)
+    us = []
+
+    def rec_choice(actions, p=None):
+        st = np.random.get_state()
+        r = orig_choice(actions, p=p)
+        rs = np.random.RandomState()
+        rs.set_state(st)
+        us.append(rs.random_sample())
+        return r
+
+    np.random.choice = rec_choice
+    try:
+        env = RT.Environment()
+        black_c = RT.Controller(RT.Player.BLACK, HashNetwork(mb))
+        white_c = RT.Controller(RT.Player.WHITE, HashNetwork(mw))
+        acts = []
+        while not env.done and env.steps < 60:
+            obs = env.observe()
+            legal = sorted(env.legal_actions, key=lambda a: a.index)
+            a_b = black_c.step(obs, env.player, legal)
+            a_w = white_c.step(obs, env.player, legal)
+            a = a_b if a_b else a_w
+            env.step(a)
+            acts.append(a.index)
+    finally:
+        np.random.choice = orig_choice
+    return np.array(acts, np.uint8), np.array(us, np.float64), int(np.sum(env.board == 1)), int(np.sum(env.board == -1))
+
+
+def _bulk_arena_chunk(job):
+    from oracle import mz_oracle as O
+    modes = ("hash", "sat", "const", "uniform")
+    mb, mw = modes[job % 4], modes[(job // 4) % 4]
+    acts, us, ws, bs = _ref_arena_game(mb, mw, 5000 + job)
+    n, oacts, ows, obs_ = O.arena_game_hashnet(R.MODES[mb], R.MODES[mw], 100, 0.25, us)
+    same = n == len(acts) and bool((oacts == acts).all())
+    return dict(games=1, moves=len(acts), mismatched_games=int(not same), mismatched_scores=int((ows, obs_) != (ws, bs)),
+                passes=int((acts == 64).sum()), black_wins=int(bs > ws), white_wins=int(ws > bs), draws=int(ws == bs))
+
+
+def gen_bulk_arena(n_games=128):
+    """SURVEY 8(f) row 3 at bulk: whole arena games played by the IMPORTED reference (test.py Controller.step: 100-simulation
+    run_mcts without noise, softmax_sample at t = 0.25) between HashNet networks of every mode pair, against
+    oracle/mz_oracle.c's arena_game_hashnet fed the same recorded uniforms: action log and final scores.  Verdict only."""
+    import json
+    import multiprocessing as mp
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    t0 = time.time()
+    tot = {}
+    with mp.Pool(8) as pool:
+        for k, st in enumerate(pool.imap_unordered(_bulk_arena_chunk, range(n_games))):
+            for key, v in st.items():
+                tot[key] = tot.get(key, 0) + int(v)
+            if k % 16 == 0:
+                print("bulk_arena: %d games, %.0f s, mismatches %d" % (tot["games"], time.time() - t0, tot["mismatched_games"]), flush=True)
+    tot.update(simulations=100, temperature=0.25, mode_pairs=16, seconds=round(time.time() - t0, 1), processes=8,
+               reference="/root/reference/test.py Controller / run_mcts / softmax_sample imported in the build container",
+               compared="every move of every game + final disc counts vs oracle/mz_oracle.c arena_game_hashnet")
+    tot["mismatches"] = tot["mismatched_games"] + tot["mismatched_scores"]
+    with open(os.path.join(HERE, "bulk_arena_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["mismatches"] == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# bulk verdict for the TRAINING STEP (main.py:230-272): reference update_weights vs muzero_amd.train on the CPU, verdict only
+# ------------------------------------------------------------------------------------------------
+def gen_bulk_train(n_runs=24):
+    """SURVEY 8(f) row 2 at bulk: n_runs x 2 consecutive reference update_weights steps (random-init reference Network, SGD as
+    train_network builds it, random batches of B in {2,3,4,8}, K in {1,3,5}) against muzero_amd.train.update_weights on the same
+    weights and batches, in its reference-shaped form (muzero_loss) and its batched form (muzero_loss_batched + deferred weight
+    gradients) -- every parameter and gradient after every step.  fp32 on the CPU in both: the plain form must agree to the bit,
+    the batched form to fp32 reassociation (a few units in the last place of a weight).  Verdict only: tests/golden/bulk_train_verdict.json."""
+    import contextlib
+    import io
+    import json
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from muzero_amd import config as C, train as T
+    from muzero_amd.network import Network
+    T.LOG = None
+    t0 = time.time()
+    tot = dict(runs=0, steps=0, tensors=0, plain_bit_equal_tensors=0, plain_worst_rel=0.0, batched_worst_rel=0.0,
+               plain_bit_equal_gradients=0, batched_worst_grad_rel_l2=0.0, batched_worst_grad_rel_max=0.0, loss_worst_abs=0.0)
+    rels, steps_off = [], 0
+    for j in range(n_runs):
+        B, K = (2, 3, 4, 8)[j % 4], (1, 3, 5)[(j // 4) % 3]
+        rng = np.random.default_rng(4000 + j)
+        torch.manual_seed(7000 + j)
+        ref = M.Network()
+        ref.train()
+        nets = {"ref": ref}
+        for name in ("plain", "batched"):
+            nets[name] = Network()
+            nets[name].load_state_dict(ref.state_dict())
+            nets[name].train()
+        opts = {k: M.optim.SGD(n.parameters(), lr=0.001, weight_decay=M.config.lr_decay_rate, momentum=M.config.momentum) if k == "ref"
+                else T.make_optimizer(n) for k, n in nets.items()}
+        C.num_unroll_steps = K
+        for step in range(2):
+            batch = (rng.integers(0, 2, (B, 9, 8, 8)).astype(np.float32), rng.integers(0, 2, (K, B, 2, 8, 8)).astype(np.float32),
+                     rng.uniform(-1, 1, (K + 1, B)).astype(np.float32),
+                     torch.softmax(torch.from_numpy(rng.normal(size=(K + 1, B, 65)).astype(np.float32)), -1).numpy())
+            w_before = [p.detach().clone() for p in ref.parameters()]
+            ref.steps = 0
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                M.update_weights(opts["ref"], ref, batch)
+            line = buf.getvalue().split()                       # 'step 0: p_loss 4.1744 v_loss 4.4605'
+            for name in ("plain", "batched"):
+                pl, vl = T.update_weights(opts[name], nets[name], batch, batched=(name == "batched"))
+                tot["loss_worst_abs"] = max(tot["loss_worst_abs"], abs(float(pl) - float(line[3])), abs(float(vl) - float(line[5])))
+                for a, b, w0 in zip(nets[name].parameters(), ref.parameters(), w_before):
+                    upd = float((b.detach() - w0).abs().max())
+                    rel = float((a.detach() - b.detach()).abs().max()) / max(upd, 1e-30)
+                    tot[name + "_worst_rel"] = max(tot[name + "_worst_rel"], rel)
+                    ga, gb = a.grad.double(), b.grad.double()      # the step's gradients are still in .grad on both sides
+                    if name == "plain":
+                        tot["tensors"] += 1
+                        tot["plain_bit_equal_tensors"] += int(torch.equal(a.detach(), b.detach()))
+                        tot["plain_bit_equal_gradients"] += int(torch.equal(a.grad, b.grad))
+                    else:
+                        rels.append(float((ga - gb).norm() / gb.norm().clamp_min(1e-300)))
+                        tot["batched_worst_grad_rel_l2"] = max(tot["batched_worst_grad_rel_l2"], rels[-1])
+                        tot["batched_worst_grad_rel_max"] = max(tot["batched_worst_grad_rel_max"], float((ga - gb).abs().max() / gb.abs().max().clamp_min(1e-300)))
+            tot["steps"] += 1
+            steps_off += int(max(rels[-len(w_before):]) > 1e-5)
+        tot["runs"] += 1
+        print("bulk_train: run %d (B %d, K %d), %.0f s: plain worst %.3g, batched worst %.3g" %
+              (j, B, K, time.time() - t0, tot["plain_worst_rel"], tot["batched_worst_rel"]), flush=True)
+    C.num_unroll_steps = 3
+    rels.sort()
+    # the batched form sums the same terms in another order; a ReLU input within fp32 rounding of zero can then sit on the other
+    # side of its gate, which switches that unit's upstream gradient (seen the same way between GPU and CPU, tests/test_gpu_train.py)
+    tot.update(batched_median_grad_rel_l2=rels[len(rels) // 2], batched_p99_grad_rel_l2=rels[int(len(rels) * 0.99)],
+               batched_steps_with_a_tensor_above_1e5=steps_off)
+    tot.update(seconds=round(time.time() - t0, 1), batch_sizes=[2, 3, 4, 8], unroll_steps=[1, 3, 5],
+               reference="/root/reference/main.py update_weights + Network imported in the build container (CPU, fp32)",
+               compared="every parameter and every gradient after every step (weights: max |mine - reference| relative to the step's largest weight change of that tensor, and in units of the fp32 spacing of the weight; gradients: relative L2 and max per tensor); losses vs the reference's printed line (4 decimals)")
+    with open(os.path.join(HERE, "bulk_train_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["plain_bit_equal_tensors"] == tot["plain_bit_equal_gradients"] == tot["tensors"]
+    assert tot["batched_median_grad_rel_l2"] <= 1e-6 and tot["batched_worst_grad_rel_l2"] <= 2e-2 and tot["loss_worst_abs"] <= 1e-4
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "bulk":
         gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
+    if what == "bulk_train":
+        gen_bulk_train(int(sys.argv[2]) if len(sys.argv) > 2 else 24)
+        sys.exit(0)
+    if what == "bulk_arena":
+        gen_bulk_arena(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
         sys.exit(0)
     if what == "bulk_replay":
         gen_bulk_replay(int(sys.argv[2]) if len(sys.argv) > 2 else 64)

@@ -30,3 +30,15 @@ def test_arena_games_and_controller_images():
         for t in range(n):
             img = O.controller_image(hw, hb, t, t % 2 == 0)
             assert (img == G["images_%d" % g][t].astype(np.float32)).all(), (g, t)
+
+
+def test_bulk_reference_verdict_is_committed_and_clean():
+    """SURVEY 8(f) row 3 at bulk: whole arena games played by the IMPORTED reference's test.py (Controller.step: 100-simulation
+    run_mcts without noise, softmax_sample at t = 0.25; tests/golden/make_golden.py bulk_arena, build container only) between
+    HashNet networks of all 16 mode pairs, against this oracle's arena_game_hashnet on the recorded uniforms; only the verdict
+    travels."""
+    import json
+    v = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bulk_arena_verdict.json")))
+    assert v["games"] >= 500 and v["moves"] >= 50 * v["games"] and v["simulations"] == 100
+    assert v["mismatches"] == v["mismatched_games"] == v["mismatched_scores"] == 0
+    assert v["passes"] > 50 and v["black_wins"] > 50 and v["white_wins"] > 50

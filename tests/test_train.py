@@ -207,3 +207,18 @@ def test_unequal_local_batches_weighted_all_reduce(tmp_path):
     n, world = 3, 2
     order = [owner_of_global_game(i, n, world) for i in range(12)]
     assert order == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (0, 3), (0, 4), (0, 5), (1, 3), (1, 4), (1, 5)]
+
+
+def test_bulk_reference_verdict_is_committed_and_clean(golden_dir):
+    """SURVEY 8(f) row 2 at bulk: 96 update_weights steps of the IMPORTED reference (main.py:230-272; tests/golden/make_golden.py
+    bulk_train, build container only; B in {2,3,4,8}, K in {1,3,5}, two consecutive steps per run so momentum and weight decay
+    act) against muzero_amd.train.update_weights on the same weights and batches: the reference-shaped form is bit-equal in every
+    weight and every gradient; the batched form (heads once over the unroll, deferred weight gradients) sums the same terms in
+    another order -- median 2.5e-7 per tensor, and in a few steps a ReLU input within fp32 rounding of zero sits on the other
+    side of its gate (worst tensor 2e-3).  Only the verdict travels."""
+    import json
+    v = json.load(open(os.path.join(golden_dir, "bulk_train_verdict.json")))
+    assert v["steps"] >= 96 and v["tensors"] == 40 * v["steps"]
+    assert v["plain_bit_equal_tensors"] == v["plain_bit_equal_gradients"] == v["tensors"] and v["plain_worst_rel"] == 0.0
+    assert v["batched_median_grad_rel_l2"] <= 1e-6 and v["batched_p99_grad_rel_l2"] <= 1e-4 and v["batched_worst_grad_rel_l2"] <= 2e-2
+    assert v["loss_worst_abs"] <= 1e-4   # the reference prints 4 decimals
