@@ -12,10 +12,15 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes):
+    """the weight gradient's partial-sum scratch: ONE buffer per device, allocated once at the size the largest call needs
+    (the slice count is capped, so that is 75.6 MB) and never replaced -- a captured hipGraph (train.GraphedUpdate) holds its
+    address.  Calls on one device share it: weight-gradient calls that overlap in time on two streams would race."""
     ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if ws is None:
+        ws = torch.empty(max(int(nbytes), int(L.lib.mz_conv3x3_wgrad_workspace(1 << 24))), dtype=torch.uint8, device=device)
         _workspaces[device] = ws
+    if ws.numel() < nbytes:
+        raise L.MzError("conv3x3_wgrad: workspace of %d bytes, %d needed" % (ws.numel(), nbytes))
     return ws
 
 
