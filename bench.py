@@ -289,6 +289,16 @@ def bench_train(args, device, rec):
         gu(rb.sample_batch(K))
     torch.cuda.synchronize()
     dt_hipg = (time.perf_counter() - t0) / iters
+    # the same kernels in split precision (three bf16 MFMA products per fp32 product: ~1e-5 of the fp32 arithmetic), graphed
+    gu3 = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs="x3")
+    for _ in range(3 + iters):
+        if _ == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        gu3(rb.sample_batch(K))
+    torch.cuda.synchronize()
+    dt_x3 = (time.perf_counter() - t0) / iters
+    del gu, gu3
     # the two hand-written training kernels alone, at the step's own sizes (HIP events over 30 launches each, torch's current
     # stream = the stream they are launched on): one convolution of one use (B boards), one weight gradient over the K uses
     from muzero_amd import convgrad as CG
@@ -319,11 +329,14 @@ def bench_train(args, device, rec):
             "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
             "hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
             "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
-            "hip_kernels": hip_kernels, "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
+            "hip_kernels": hip_kernels, "hip_x3_graph_ms_per_step": dt_x3 * 1e3, "hip_x3_graph_samples_per_sec": B / dt_x3,
+            "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
             "note": "ms_per_step: MIOpen convolutions through PyTorch autograd, fp32 as the reference; bf16_autocast: torch.autocast over the same "
                     "(fp32 master weights); hip_convs: the towers' 128 -> 128 convolutions -- forward, data gradient, weight gradient -- on the "
                     "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
-                    "gradients closer to the fp32 step's than autocast's, tests/test_gpu_convgrad.py), everything else as the fp32 step"}
+                    "gradients closer to the fp32 step's than autocast's, tests/test_gpu_convgrad.py), everything else as the fp32 step; "
+                    "hip_x3: those kernels in split precision (hi = bf16(v), lo = bf16(v - hi), a b = a_hi b_hi + a_lo b_hi + a_hi b_lo: a convolution "
+                    "within 3e-6 of fp64, against 2e-3 for one bf16 product); *_graph: the step replayed as one hipGraph (train.GraphedUpdate)"}
 
 
 def bench_loop(args, device, dtype):

@@ -457,13 +457,25 @@ int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t
 int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream);
 int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream);
 /* mz_conv3x3_forward with the residual block's elementwise work fused into the store phase (all tensors (n,128,8,8) f32 NCHW,
- * skip / mask nullable, neither may alias y):   y = [relu]( [mask > 0 ?] (conv(x) + bias [+ skip]) : 0 )
+ * skip / mask nullable, mask may not alias y; x_part 0 = x rounded to bf16, 1 = see split precision below):
+ *     y = [relu]( [mask > 0 ?] (conv(x) + bias [+ skip]) : 0 )
  *   forward : t = relu(conv1(h))             -> relu = 1
  *             y = relu(h + conv2(t))         -> skip = h, relu = 1                                   (network.py:35-47)
  *   backward: g_t   = dgrad2(g_pre) * (t > 0)                 -> mask = t
  *             g_pre' = (g_pre + dgrad1(g_t)) * (y_prev > 0)   -> skip = g_pre, mask = y_prev  (the previous block's gate) */
-int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, const float *skip, const float *mask, float *y, int64_t n,
-                     int32_t relu, void *stream);
+int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, int32_t x_part, const float *skip, const float *mask, float *y,
+                     int64_t n, int32_t relu, void *stream);
+
+/* Split precision ("bf16x3"): the same kernels at close to the reference's fp32 arithmetic.  A value v is carried as
+ * hi = bf16(v) and lo = bf16(v - hi) (16 mantissa bits together), and a product a * b as a_hi b_hi + a_lo b_hi + a_hi b_lo
+ * (relative error ~2^-16 per product; sums in f32 as before).
+ *   mz_conv3x3_pack_part(part = 1) packs the weights' lo images; x_part = 1 makes mz_conv3x3_fused convolve the lo part of x.
+ *   One convolution = three launches accumulating through skip (which may alias y):
+ *       y  = conv(x hi, W hi) + bias [+ residual skip];   y += conv(x lo, W hi);   y = epilogue(y + conv(x hi, W lo))
+ *   mz_conv3x3_wgrad_x3 forms the three products inside one pass over the operands. */
+int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream);
+int mz_conv3x3_wgrad_x3(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
+                        int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

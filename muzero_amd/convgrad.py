@@ -29,9 +29,10 @@ def _check(t, name):
         raise L.MzError("%s: need contiguous cuda float32 tensors of shape (n, 128, 8, 8), got %s %s on %s" % (name, tuple(t.shape), t.dtype, t.device))
 
 
-def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False):
+def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False, x3=False):
     """dw (128,128,3,3) (+)= weight gradient, db (128) (+)= bias gradient of one 3x3 / padding 1 convolution summed over its uses:
-    xs[k] = the k-th use's input, gs[k] = the gradient of its output (mz_conv3x3_wgrad)."""
+    xs[k] = the k-th use's input, gs[k] = the gradient of its output (mz_conv3x3_wgrad).  x3: split precision (every product as
+    g_hi x_hi + g_lo x_hi + g_hi x_lo with hi = bf16(v), lo = bf16(v - hi): close to fp32; mz_conv3x3_wgrad_x3)."""
     if len(xs) != len(gs) or not 1 <= len(xs) <= 8:
         raise L.MzError("conv3x3_wgrad: 1..8 (input, grad_output) pairs, got %d / %d" % (len(xs), len(gs)))
     for x, g in zip(xs, gs):
@@ -50,38 +51,50 @@ def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False):
     xp = (C.c_void_p * k)(*[x.data_ptr() for x in xs])
     gp = (C.c_void_p * k)(*[g.data_ptr() for g in gs])
     nb = (C.c_int64 * k)(*[int(x.shape[0]) for x in xs])
-    L.call("mz_conv3x3_wgrad", xp, gp, nb, k, L.dptr(dw), L.dptr(db), 1 if accumulate else 0, L.dptr(ws), ws.numel(), L.current_stream())
+    L.call("mz_conv3x3_wgrad_x3" if x3 else "mz_conv3x3_wgrad", xp, gp, nb, k, L.dptr(dw), L.dptr(db), 1 if accumulate else 0, L.dptr(ws), ws.numel(), L.current_stream())
     return dw, db
 
 
 PACKED_ELEMS = 40 * 4096   # MZ_CONV3X3_PACKED_BYTES / 2
 
 
-def pack_conv(weight, out=None):
-    """conv weight (128,128,3,3) f32 on the GPU -> (forward image, data-gradient image), bf16 (mz_conv3x3_pack)"""
+def pack_conv(weight, out=None, split=False):
+    """conv weight (128,128,3,3) f32 on the GPU -> (forward image, data-gradient image), bf16 (mz_conv3x3_pack); split=True:
+    (forward, data-gradient, forward lo, data-gradient lo) -- the images of bf16(w) and of the remainder bf16(w - bf16(w))"""
     w = weight.detach()
     if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
         raise L.MzError("pack_conv: need a contiguous cuda float32 (128,128,3,3) weight")
     if out is None:
-        out = torch.empty((2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
+        out = torch.empty((4 if split else 2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
     L.call("mz_conv3x3_pack", L.dptr(w), L.dptr(out[0]), L.dptr(out[1]), L.current_stream())
-    return out[0], out[1]
+    if not split:
+        return out[0], out[1]
+    L.call("mz_conv3x3_pack_part", L.dptr(w), L.dptr(out[2]), L.dptr(out[3]), 1, L.current_stream())
+    return out[0], out[1], out[2], out[3]
 
 
-def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None):
+def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, packed_lo=None):
     """y = [relu]( [mask > 0 ?] (conv3x3(x) + bias [+ skip]) : 0 ) with the packed weight image (forward image: the convolution;
-    data-gradient image applied to a grad_output: the input gradient).  x, skip, mask (n,128,8,8) f32 NCHW (mz_conv3x3_fused)."""
+    data-gradient image applied to a grad_output: the input gradient).  x, skip, mask (n,128,8,8) f32 NCHW (mz_conv3x3_fused).
+    packed_lo (the matching lo image of pack_conv(split=True)): split precision, three launches accumulating in y --
+    conv(x hi, W hi) + bias + skip, + conv(x lo, W hi), epilogue(+ conv(x hi, W lo))."""
     _check(x, "conv3x3 input")
     for t, name in ((skip, "skip"), (mask, "mask")):
         if t is not None:
             _check(t, "conv3x3 " + name)
             if t.shape != x.shape:
                 raise L.MzError("conv3x3: %s has another batch size" % name)
-    if packed.dtype != torch.bfloat16 or packed.numel() != PACKED_ELEMS or not packed.is_cuda or not packed.is_contiguous():
-        raise L.MzError("conv3x3: packed must be one of pack_conv's images")
+    for pk in (packed, packed_lo):
+        if pk is not None and (pk.dtype != torch.bfloat16 or pk.numel() != PACKED_ELEMS or not pk.is_cuda or not pk.is_contiguous()):
+            raise L.MzError("conv3x3: packed must be one of pack_conv's images")
     if bias is not None and (bias.dtype != torch.float32 or tuple(bias.shape) != (128,) or not bias.is_cuda):
         raise L.MzError("conv3x3: bias must be a cuda float32 (128,) tensor")
     y = torch.empty_like(x) if out is None else out
-    L.call("mz_conv3x3_fused", L.dptr(packed), L.dptr(bias.detach() if bias is not None else None), L.dptr(x), L.dptr(skip), L.dptr(mask), L.dptr(y),
-           int(x.shape[0]), 1 if relu else 0, L.current_stream())
+    n, st, b = int(x.shape[0]), L.current_stream(), L.dptr(bias.detach() if bias is not None else None)
+    if packed_lo is None:
+        L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 0, L.dptr(skip), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
+    else:
+        L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 0, L.dptr(skip), None, L.dptr(y), n, 0, st)
+        L.call("mz_conv3x3_fused", L.dptr(packed), None, L.dptr(x), 1, L.dptr(y), None, L.dptr(y), n, 0, st)
+        L.call("mz_conv3x3_fused", L.dptr(packed_lo), None, L.dptr(x), 0, L.dptr(y), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
     return y

@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(512) k_tower(KArgs) {
 // with the flipped/transposed pack -- the data gradient of the same convolution.  One workgroup per 8-board tile: the input is
 // rounded to bf16 into the [pos][ch] image (thread = position; 8 channels per 16-byte chunk), the weights stream through the
 // ring, and the fp32 accumulators go straight back to NCHW (lane = position, so a store instruction writes 16-cell runs).
-struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; const float *skip; const float *mask; };
+struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu; const float *skip; const float *mask; int x_part; };
 
 // Epilogue (EPI bit 0: skip, bit 1: mask), all on (n,128,8,8) f32 NCHW tensors: y = [relu]( [mask > 0 ?] (acc [+ skip]) : 0 ).
 // That is the residual block's forward tail relu(h + conv(t)) and, in the backward pass, the ReLU gates and the skip path's
@@ -880,6 +880,16 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[c][k] = src[((c0 + c) * 8 + k) * 64];
+                if (a.x_part) {   // the rounding remainder x - bf16(x) (exact in f32): the second term of a split-precision product
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) {
+                            const uint32_t hi = pack_bf16(v[c][k], v[c][k + 1]);
+                            v[c][k] -= bf16_up(hi & 0xFFFFu);
+                            v[c][k + 1] -= __uint_as_float(hi & 0xFFFF0000u);
+                        }
+                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     *reinterpret_cast<uint4 *>(row + (((cbase + c0 + c) ^ key) << 4)) =
@@ -940,7 +950,7 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
 //   forward : stage (ky*3+kx)*4 + ci/32, row co, element = W[co][ci][ky][kx]
 //   backward: stage (ky*3+kx)*4 + co/32, row ci, element = W[co][ci][2-ky][2-kx]   (the data gradient as a convolution of g)
 // slot s of a row holds the 8-channel chunk s ^ {0,2,3,1}[(row >> 2) & 3]; the 4 trailing stages are zero (prefetch padding)
-__global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ wsrc, uint16_t *__restrict__ fwd, uint16_t *__restrict__ bwd) {
+__global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ wsrc, uint16_t *__restrict__ fwd, uint16_t *__restrict__ bwd, int part) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (stage, row, slot, e)
     if (idx >= 40 * 4096) return;
     const int e = idx & 7, slot = (idx >> 3) & 3, row = (idx >> 5) & 127, stage = idx >> 12;
@@ -948,8 +958,13 @@ __global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ 
     if (stage < 36) {
         const int tap = stage >> 2, quarter = stage & 3, ky = tap / 3, kx = tap % 3;
         const int ch = quarter * 32 + ((slot ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3) + e;
-        f = (uint16_t)bf16_rne(wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx]);
-        bk = (uint16_t)bf16_rne(wsrc[((ch * 128 + row) * 3 + (2 - ky)) * 3 + (2 - kx)]);
+        float wf = wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx], wb = wsrc[((ch * 128 + row) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        if (part) {   // the rounding remainder w - bf16(w): exact in f32, then rounded to bf16 itself
+            wf -= bf16_up(bf16_rne(wf));
+            wb -= bf16_up(bf16_rne(wb));
+        }
+        f = (uint16_t)bf16_rne(wf);
+        bk = (uint16_t)bf16_rne(wb);
     }
     fwd[idx] = f;
     bwd[idx] = bk;
@@ -957,16 +972,21 @@ __global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ 
 
 }  // namespace
 
-extern "C" int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream) {
+extern "C" int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream) {
     MZ_REQUIRE(w && packed_fwd && packed_bwd, "mz_conv3x3_pack: null pointer");
     MZ_REQUIRE((((uintptr_t)packed_fwd | (uintptr_t)packed_bwd) & 15) == 0, "mz_conv3x3_pack: outputs must be 16-byte aligned");
-    hipLaunchKernelGGL(k_conv3x3_pack, dim3(40 * 4096 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t *)packed_fwd, (uint16_t *)packed_bwd);
+    MZ_REQUIRE(part == 0 || part == 1, "mz_conv3x3_pack: part must be 0 (the bf16 rounding) or 1 (its remainder)");
+    hipLaunchKernelGGL(k_conv3x3_pack, dim3(40 * 4096 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t *)packed_fwd, (uint16_t *)packed_bwd, (int)part);
     MZ_LAUNCH_CHECK("k_conv3x3_pack");
     return MZ_OK;
 }
 
-extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, const float *skip, const float *mask, float *y, int64_t n,
-                               int32_t relu, void *stream) {
+extern "C" int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream) {
+    return mz_conv3x3_pack_part(w, packed_fwd, packed_bwd, 0, stream);
+}
+
+extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, int32_t x_part, const float *skip, const float *mask, float *y,
+                               int64_t n, int32_t relu, void *stream) {
     MZ_REQUIRE(n >= 0, "mz_conv3x3_forward: n < 0");
     if (n == 0) return MZ_OK;
     MZ_REQUIRE(packed && x && y, "mz_conv3x3_forward: null pointer");
@@ -979,8 +999,9 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
     const bool small = (n + 7) / 8 < cus;
     const int64_t n_tiles = small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
-    MZ_REQUIRE(skip != y && mask != y, "mz_conv3x3_fused: skip / mask alias the output");
-    const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu, skip, mask};
+    MZ_REQUIRE(mask != y, "mz_conv3x3_fused: mask aliases the output");   // skip may: every lane reads its own cells before it writes them
+    MZ_REQUIRE(x_part == 0 || x_part == 1, "mz_conv3x3_fused: x_part must be 0 or 1");
+    const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu, skip, mask, (int)x_part};
     const dim3 grid((unsigned)n_tiles), block(512);
     const hipStream_t st = (hipStream_t)stream;
     switch ((small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
@@ -998,7 +1019,7 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
 }
 
 extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream) {
-    return mz_conv3x3_fused(packed, bias, x, nullptr, nullptr, y, n, relu, stream);
+    return mz_conv3x3_fused(packed, bias, x, 0, nullptr, nullptr, y, n, relu, stream);
 }
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,

@@ -67,6 +67,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {   // v_cvt_pk_
 __device__ __forceinline__ u32x4 to_bf16(const f32x4 lo, const f32x4 hi) {
     return u32x4{pack_bf16(lo.x, lo.y), pack_bf16(lo.z, lo.w), pack_bf16(hi.x, hi.y), pack_bf16(hi.z, hi.w)};
 }
+// bf16(v - bf16(v)) for the eight values of a fragment whose bf16 rounding is h: the second term of a split-precision product
+__device__ __forceinline__ u32x4 remainder_bf16(const f32x4 lo, const f32x4 hi, const u32x4 h) {
+    auto up_lo = [](uint32_t p) { return __uint_as_float(p << 16); };
+    auto up_hi = [](uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); };
+    return u32x4{pack_bf16(lo.x - up_lo(h.x), lo.y - up_hi(h.x)), pack_bf16(lo.z - up_lo(h.y), lo.w - up_hi(h.y)),
+                 pack_bf16(hi.x - up_lo(h.z), hi.y - up_hi(h.z)), pack_bf16(hi.z - up_lo(h.w), hi.w - up_hi(h.w))};
+}
 // the fragment moved by one cell: element e of the result = element e + 1 (up) / e - 1 (down) of v, zero at the board's edge
 __device__ __forceinline__ u32x4 cells_up(const u32x4 v) {
     return u32x4{__builtin_amdgcn_alignbit(v.y, v.x, 16), __builtin_amdgcn_alignbit(v.z, v.y, 16), __builtin_amdgcn_alignbit(v.w, v.z, 16), v.w >> 16};
@@ -80,6 +87,9 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_addr_wave, const void *__
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr_wave), "v"(lane_off), "s"(src_uniform) : "memory");
 }
 
+// X3: split precision -- every fragment as hi = bf16(v) and lo = bf16(v - hi), every product as g_hi x_hi + g_lo x_hi + g_hi x_lo
+// (three MFMAs per tile instead of one, on operands that are in LDS anyway: the pass over HBM stays one)
+template <bool X3>
 __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
     __shared__ __attribute__((aligned(16))) char lds[WG_LDS];
     const kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -145,12 +155,14 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
                 const f32x4 hi = *reinterpret_cast<const f32x4 *>(buf + g_row0 + w * 4096 + p1);
                 gsum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
             }
-            bf16x8 af[4];
+            bf16x8 af[4], afl[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const f32x4 lo = *reinterpret_cast<const f32x4 *>(buf + g_row0 + ct * 4096 + p0);
                 const f32x4 hi = *reinterpret_cast<const f32x4 *>(buf + g_row0 + ct * 4096 + p1);
-                af[ct] = __builtin_bit_cast(bf16x8, to_bf16(lo, hi));
+                const u32x4 h = to_bf16(lo, hi);
+                af[ct] = __builtin_bit_cast(bf16x8, h);
+                if (X3) afl[ct] = __builtin_bit_cast(bf16x8, remainder_bf16(lo, hi, h));
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -158,7 +170,8 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
                 const bool inside = yy >= 0 && yy <= 7;
                 const char *q0 = inside ? buf + x_row0 + ((2 * yy + s) & 15) * 16 : lds + OFF_ZERO;
                 const char *q1 = inside ? buf + x_row0 + ((2 * yy + 1 + s) & 15) * 16 : lds + OFF_ZERO + 16;
-                const u32x4 raw = to_bf16(*reinterpret_cast<const f32x4 *>(q0), *reinterpret_cast<const f32x4 *>(q1));
+                const f32x4 xlo = *reinterpret_cast<const f32x4 *>(q0), xhi = *reinterpret_cast<const f32x4 *>(q1);
+                const u32x4 raw = to_bf16(xlo, xhi);
                 const bf16x8 bdn = __builtin_bit_cast(bf16x8, cells_down(raw)), bmid = __builtin_bit_cast(bf16x8, raw),
                              bup = __builtin_bit_cast(bf16x8, cells_up(raw));
 #pragma unroll
@@ -166,6 +179,23 @@ __global__ void __launch_bounds__(512) k_conv_wgrad(WgradArgs) {
                     acc[ct][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bdn, acc[ct][dy * 3 + 0], 0, 0, 0);
                     acc[ct][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bmid, acc[ct][dy * 3 + 1], 0, 0, 0);
                     acc[ct][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], bup, acc[ct][dy * 3 + 2], 0, 0, 0);
+                }
+                if (X3) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {   // g_lo x_hi
+                        acc[ct][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[ct], bdn, acc[ct][dy * 3 + 0], 0, 0, 0);
+                        acc[ct][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[ct], bmid, acc[ct][dy * 3 + 1], 0, 0, 0);
+                        acc[ct][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[ct], bup, acc[ct][dy * 3 + 2], 0, 0, 0);
+                    }
+                    const u32x4 rl = remainder_bf16(xlo, xhi, raw);
+                    const bf16x8 ldn = __builtin_bit_cast(bf16x8, cells_down(rl)), lmid = __builtin_bit_cast(bf16x8, rl),
+                                 lup = __builtin_bit_cast(bf16x8, cells_up(rl));
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {   // g_hi x_lo
+                        acc[ct][dy * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], ldn, acc[ct][dy * 3 + 0], 0, 0, 0);
+                        acc[ct][dy * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], lmid, acc[ct][dy * 3 + 1], 0, 0, 0);
+                        acc[ct][dy * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct], lup, acc[ct][dy * 3 + 2], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -230,8 +260,8 @@ extern "C" int64_t mz_conv3x3_wgrad_workspace(int64_t n_boards) {
     return slices * (int64_t)(PART_FLOATS + 128) * 4;
 }
 
-extern "C" int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
-                                int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
+static int wgrad_launch(bool x3, const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
+                        int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
     MZ_REQUIRE(x && g && n_boards && dw, "mz_conv3x3_wgrad: null pointer");
     MZ_REQUIRE(n_seg >= 1 && n_seg <= MAX_SEG, "mz_conv3x3_wgrad: %d uses outside [1, %d]", n_seg, MAX_SEG);
     WgradArgs a{};
@@ -255,10 +285,21 @@ extern "C" int mz_conv3x3_wgrad(const float *const *x, const float *const *g, co
     a.per_slice = (int)per;
     a.partial = (float *)workspace;
     a.db_partial = a.partial + slices * (int64_t)PART_FLOATS;
-    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)(16 * ((slices + 7) / 8))), dim3(512), 0, (hipStream_t)stream, a);
+    if (x3) hipLaunchKernelGGL(k_conv_wgrad<true>, dim3((unsigned)(16 * ((slices + 7) / 8))), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_conv_wgrad<false>, dim3((unsigned)(16 * ((slices + 7) / 8))), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_conv_wgrad");
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((PART_FLOATS + 128 + 63) / 64), dim3(256), 0, (hipStream_t)stream, a.partial, a.db_partial, (int)slices, dw,
                        db, (int)accumulate);
     MZ_LAUNCH_CHECK("k_wgrad_reduce");
     return MZ_OK;
+}
+
+extern "C" int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
+                                int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
+    return wgrad_launch(false, x, g, n_boards, n_seg, dw, db, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mz_conv3x3_wgrad_x3(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
+                                   int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream) {
+    return wgrad_launch(true, x, g, n_boards, n_seg, dw, db, accumulate, workspace, workspace_bytes, stream);
 }

@@ -44,7 +44,7 @@ class MuZeroLoop:
         gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw.
         train_convs "fp32": the reference's arithmetic (PyTorch/MIOpen); "hip": the towers' 128 -> 128 convolutions and their
         gradients on the hand-written matrix-core kernels (bf16 operands, fp32 sums and master weights: train.update_weights
-        hip_convs).  train_graph: the training step replayed as one hipGraph (train.GraphedUpdate; one process, replicated
+        hip_convs); "hip_x3": those kernels in split precision (three bf16 products per fp32 product: close to fp32).  train_graph: the training step replayed as one hipGraph (train.GraphedUpdate; one process, replicated
         window only -- the captured step holds no collective)."""
         self.group = group
         self.world = dist.get_world_size(group) if T._dist_on(group) else 1
@@ -66,9 +66,9 @@ class MuZeroLoop:
         if replay_mode not in ("replicated", "sharded"):
             raise ValueError("replay_mode must be 'replicated' or 'sharded'")
         self.replay_mode = replay_mode
-        if train_convs not in ("fp32", "hip"):
-            raise ValueError("train_convs must be 'fp32' or 'hip'")
-        self.hip_convs = train_convs == "hip"
+        if train_convs not in ("fp32", "hip", "hip_x3"):
+            raise ValueError("train_convs must be 'fp32', 'hip' or 'hip_x3'")
+        self.hip_convs = {"fp32": False, "hip": True, "hip_x3": "x3"}[train_convs]
         if train_graph and (self.world > 1 or replay_mode != "replicated"):
             raise ValueError("train_graph needs one process and the replicated window")
         self.train_graph = bool(train_graph)

@@ -114,7 +114,7 @@ class _ConvDeferW(torch.autograd.Function):
             from .convgrad import conv3x3
             x = x.contiguous()
             ctx.save_for_backward(x)
-            return conv3x3(x, packed[0], conv.bias)
+            return conv3x3(x, packed[0], conv.bias, packed_lo=packed[2] if len(packed) > 2 else None)
         ctx.save_for_backward(x, conv.weight)
         return torch.ops.aten.convolution(x, conv.weight, conv.bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
@@ -126,7 +126,7 @@ class _ConvDeferW(torch.autograd.Function):
             from .convgrad import conv3x3
             x, = ctx.saved_tensors
             if ctx.needs_input_grad[0]:
-                gx = conv3x3(g, ctx.packed[1])
+                gx = conv3x3(g, ctx.packed[1], packed_lo=ctx.packed[3] if len(ctx.packed) > 2 else None)
         else:
             x, w = ctx.saved_tensors
             if ctx.needs_input_grad[0]:
@@ -143,8 +143,11 @@ class DeferredWeightGrads:
     concatenation) -- instead of MIOpen's fp32 kernels."""
 
     def __init__(self, hip=False):
+        if hip not in (False, True, "bf16", "x3"):
+            raise ValueError("hip must be False, True / 'bf16' or 'x3'")
         self.sinks = {}
         self.hip = bool(hip)
+        self.x3 = hip == "x3"      # split precision: three bf16 MFMA products per fp32 product (muzero_amd/convgrad.py)
         self.packed = {}
 
     def _is_tower_conv(self, conv, x):
@@ -154,7 +157,7 @@ class DeferredWeightGrads:
         packed = self.packed.get(id(conv))
         if packed is None:   # once per step: the weights change with every optimiser step
             from .convgrad import pack_conv
-            packed = self.packed[id(conv)] = pack_conv(conv.weight)
+            packed = self.packed[id(conv)] = pack_conv(conv.weight, split=self.x3)
         return packed
 
     def park(self, conv, x, g):
@@ -175,7 +178,7 @@ class DeferredWeightGrads:
                 for prm in (conv.weight, conv.bias):
                     if prm is not None and prm.grad is None:
                         prm.grad = torch.zeros_like(prm)
-                conv3x3_wgrad([x.contiguous() for x, _ in sink], [g for _, g in sink], conv.weight.grad, conv.bias.grad if has_b else None, accumulate=True)
+                conv3x3_wgrad([x.contiguous() for x, _ in sink], [g for _, g in sink], conv.weight.grad, conv.bias.grad if has_b else None, accumulate=True, x3=self.x3)
                 sink.clear()
                 continue
             X = torch.cat([x for x, _ in sink]) if len(sink) > 1 else sink[0][0]
@@ -206,8 +209,9 @@ class _TowerHip(torch.autograd.Function):
         for blk in blocks:
             c1, c2 = blk.block[0], blk.block[2]
             p1, p2 = dw.pack(c1), dw.pack(c2)
-            t = conv3x3(y, p1[0], c1.bias, relu=True)
-            y = conv3x3(t, p2[0], c2.bias, relu=True, skip=y)
+            lo1, lo2 = (p1[2], p2[2]) if len(p1) > 2 else (None, None)
+            t = conv3x3(y, p1[0], c1.bias, relu=True, packed_lo=lo1)
+            y = conv3x3(t, p2[0], c2.bias, relu=True, skip=y, packed_lo=lo2)
             saved += [t, y]
             packs.append((p1, p2))
         ctx.save_for_backward(*saved)
@@ -223,9 +227,10 @@ class _TowerHip(torch.autograd.Function):
             c1, c2 = ctx.blocks[k].block[0], ctx.blocks[k].block[2]
             p1, p2 = ctx.packs[k]
             y_prev, t = saved[2 * k], saved[2 * k + 1]
-            g_t = conv3x3(g_pre, p2[1], mask=t)
+            lo1, lo2 = (p1[3], p2[3]) if len(p1) > 2 else (None, None)
+            g_t = conv3x3(g_pre, p2[1], mask=t, packed_lo=lo2)
             ctx.dw.park(c2, t, g_pre)
-            g_prev = conv3x3(g_t, p1[1], skip=g_pre, mask=y_prev if k > 0 else None)   # h0's own gate belongs to the caller's ReLU
+            g_prev = conv3x3(g_t, p1[1], skip=g_pre, mask=y_prev if k > 0 else None, packed_lo=lo1)   # h0's own gate belongs to the caller's ReLU
             ctx.dw.park(c1, y_prev, g_t)
             g_pre = g_prev
         return g_pre, None, None
@@ -287,7 +292,8 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
     on a GPU in fp32, the plain reference-shaped muzero_loss elsewhere.
     hip_convs: the gradients of the towers' 3x3, 128 -> 128 convolutions through the hand-written matrix-core kernels
     (muzero_amd/convgrad.py: operands rounded to bf16, fp32 sums; fp32 master weights and optimiser) instead of MIOpen's fp32
-    kernels; implies batched.  False = the reference's fp32 arithmetic."""
+    kernels; implies batched.  "x3": the same kernels in split precision (every fp32 product as three bf16 MFMA products: close to
+    fp32, tests/test_gpu_train.py holds it to the reference's recorded gradients).  False = the reference's fp32 arithmetic."""
     if bucket is not None:
         bucket.zero()
     else:
@@ -308,7 +314,7 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
                 batched = next(network.parameters()).is_cuda and os.environ.get("MZ_TRAIN_PLAIN") != "1"
             if hip_convs:
                 batched = True
-            dw = DeferredWeightGrads(hip=hip_convs) if batched else None
+            dw = DeferredWeightGrads(hip=hip_convs if hip_convs else False) if batched else None
             p_loss, v_loss = muzero_loss_batched(network, batch, dw) if batched else muzero_loss(network, batch)
         total = p_loss + v_loss
         (total if loss_scale == 1.0 else total * float(loss_scale)).backward()

@@ -194,3 +194,53 @@ def test_conv3x3_fused_epilogues(n):
     assert torch.equal(conv3x3(x, pf, bias, relu=True, skip=skip), (y + skip).clamp_min(0))
     assert torch.equal(conv3x3(x, pf, bias, mask=mask), torch.where(mask > 0, y, torch.zeros_like(y)))
     assert torch.equal(conv3x3(x, pf, bias, skip=skip, mask=mask), torch.where(mask > 0, y + skip, torch.zeros_like(y)))
+
+
+def test_split_precision_kernels_are_close_to_fp32():
+    """bf16x3: hi = bf16(v), lo = bf16(v - hi), a*b = a_hi b_hi + a_lo b_hi + a_hi b_lo -- on arbitrary fp32 values the convolution,
+    its data gradient and its weight gradient are two orders of magnitude closer to the fp64 result than the one-product form"""
+    from muzero_amd.convgrad import conv3x3, conv3x3_wgrad, pack_conv
+    g = torch.Generator(device="cuda").manual_seed(21)
+    w = torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03
+    bias = torch.randn(128, device="cuda", generator=g)
+    x = torch.randn(37, 128, 8, 8, device="cuda", generator=g)
+    gy = torch.randn(37, 128, 8, 8, device="cuda", generator=g)
+    skip = torch.randn(37, 128, 8, 8, device="cuda", generator=g)
+    pf, pb, pfl, pbl = pack_conv(w, split=True)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    e1 = (conv3x3(x, pf, bias).double() - ref).norm().item() / ref.norm().item()
+    e3 = (conv3x3(x, pf, bias, packed_lo=pfl).double() - ref).norm().item() / ref.norm().item()
+    print("conv: relative L2 error bf16 %.3g, bf16x3 %.3g" % (e1, e3))
+    assert e3 <= 2e-5 and e3 <= e1 / 50
+    # the fused epilogue runs once, on the sum of the three products
+    got = conv3x3(x, pf, bias, relu=True, skip=skip, mask=skip.relu(), packed_lo=pfl)
+    want = torch.where(skip > 0, (ref + skip.double()).clamp_min(0), torch.zeros_like(ref))
+    assert (got.double() - want).norm().item() <= 2e-5 * want.norm().item()
+    gx, gw, gb = torch.ops.aten.convolution_backward(gy.double(), x.double(), w.double(), [128], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, True])
+    assert (conv3x3(gy, pb, packed_lo=pbl).double() - gx).norm().item() <= 2e-5 * gx.norm().item()
+    dw, db = torch.empty_like(w), torch.empty(128, device="cuda")
+    conv3x3_wgrad([x[:20], x[20:]], [gy[:20], gy[20:]], dw, db, x3=True)
+    ew = (dw.double() - gw).norm().item() / gw.norm().item()
+    print("weight gradient: relative L2 error bf16x3 %.3g" % ew)
+    assert ew <= 2e-5 and (db.double() - gb).abs().max().item() <= 1e-5 * gb.abs().max().item() + 1e-4
+
+
+def test_training_gradients_in_split_precision_match_the_fp32_step():
+    """the K = 5 unrolled loss with the towers in split precision against the fp32 PyTorch/MIOpen step (itself Winograd
+    arithmetic, not exact sums): measured on MI355X worst tensor 1.0e-3, median 1.7e-4 -- 50-90 x closer than the one-product
+    bf16 form (5.3e-2 / 1.5e-2)"""
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    torch.manual_seed(1261)
+    net = Network().to("cuda")
+    net.train()
+    B, K = 64, 5
+    g = torch.Generator(device="cpu").manual_seed(3)
+    batch = (torch.rand(B, 9, 8, 8, generator=g).round().cuda(), torch.rand(K, B, 2, 8, 8, generator=g).round().cuda(),
+             (torch.rand(K + 1, B, generator=g) * 2 - 1).cuda(), torch.softmax(torch.rand(K + 1, B, 65, generator=g), -1).cuda())
+    pl0, vl0, ref = _grads(net, batch, hip=False)
+    pl1, vl1, got = _grads(net, batch, hip="x3")
+    assert abs(pl0 - pl1) <= 1e-5 * abs(pl0) and abs(vl0 - vl1) <= 1e-5 * abs(vl0)
+    rel = sorted(float((got[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-12)) for k in ref)
+    print("split precision vs fp32: per-tensor relative L2 worst %.3g median %.3g" % (rel[-1], rel[len(rel) // 2]))
+    assert rel[-1] <= 5e-3 and rel[len(rel) // 2] <= 5e-4

@@ -43,14 +43,17 @@ def _sums(tensors):
     return np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in tensors])
 
 
-def _check(got, want, what):
+def _check(got, want, what, tol=TOL):
     err = np.abs(got[:, 0] - want[:, 0]) / (want[:, 1] + 1e-9)
-    assert err.max() <= TOL, "%s: worst relative sum error %.3g at parameter %d" % (what, err.max(), int(err.argmax()))
+    assert err.max() <= tol, "%s: worst relative sum error %.3g at parameter %d" % (what, err.max(), int(err.argmax()))
     assert np.allclose(got[:, 1], want[:, 1], rtol=5e-3, atol=1e-9), what
 
 
-@pytest.mark.parametrize("flat", [True, False])
-def test_update_weights_on_gpu_matches_reference(golden_dir, flat):
+@pytest.mark.parametrize("flat,hip", [(True, False), (False, False), (True, "x3")])
+def test_update_weights_on_gpu_matches_reference(golden_dir, flat, hip):
+    """hip "x3": the towers' convolutions and their gradients on the hand-written kernels in split precision (three bf16 MFMA
+    products per fp32 product) -- held to the reference's recorded weights and losses with the tolerances of the fp32
+    PyTorch/MIOpen step, and to its recorded gradient sums within 5 x that tolerance (ReLU gates: see below)"""
     from muzero_amd import train as T
     from muzero_amd.network import Network
     G = np.load(os.path.join(golden_dir, "replay.npz"))
@@ -89,7 +92,7 @@ def test_update_weights_on_gpu_matches_reference(golden_dir, flat):
             pl, vl = T.muzero_loss(twin, tuple(t.cpu() for t in batch))
             (pl + vl).backward()
             pl, vl = pl.detach(), vl.detach()
-            p_loss, v_loss = T.update_weights(opt, net, batch, bucket)
+            p_loss, v_loss = T.update_weights(opt, net, batch, bucket, hip_convs=hip)
             opt.step = orig
             assert abs(float(pl) - float(p_loss)) <= 1e-4 and abs(float(vl) - float(v_loss)) <= 1e-4
             worst = worst_l2 = 0.0
@@ -98,9 +101,15 @@ def test_update_weights_on_gpu_matches_reference(golden_dir, flat):
                 worst = max(worst, float((ga - gb).abs().max() / gb.abs().max().clamp_min(1e-12)))
                 worst_l2 = max(worst_l2, float((ga - gb).norm() / gb.norm().clamp_min(1e-12)))
             print("step %d: gradient vs CPU twin: worst element %.3g of max, worst tensor L2 %.3g" % (step, worst, worst_l2))
-            assert worst <= ELEM_TOL, "step %d: worst gradient element error %.3g of the tensor's max" % (step, worst)
-            assert worst_l2 <= L2_TOL, "step %d: worst relative L2 gradient error %.3g" % (step, worst_l2)
-            _check(seen["g"], G["train_grad_sums"][step], "gradients of step %d" % step)
+            # split precision carries ~1e-5 relative error where fp32 carries ~1e-6 (a step without a flipped gate agrees with the
+            # CPU twin to 1.1e-5 / 7.9e-6: step 1), so more of the step's 1.5 M ReLU inputs sit on the other side of their gate, and
+            # with 4 samples per batch each flip is visible in
+            # single gradient elements (measured: 0.13 of a tensor's max, 3.2e-2 L2) and in the recorded sums (2.8e-3 of the abs-sum
+            # against 5.4e-4 for the fp32 step): split precision is held to 5 x TOL there, the losses to the fp32 bound
+            etol, ltol = (4 * ELEM_TOL, 6 * L2_TOL) if hip else (ELEM_TOL, L2_TOL)
+            assert worst <= etol, "step %d: worst gradient element error %.3g of the tensor's max" % (step, worst)
+            assert worst_l2 <= ltol, "step %d: worst relative L2 gradient error %.3g" % (step, worst_l2)
+            _check(seen["g"], G["train_grad_sums"][step], "gradients of step %d" % step, 5 * TOL if hip else TOL)
             _check(_sums([p.detach() for p in params]), G["train_weight_sums"][step], "weights after step %d" % step)
             ref = str(G["train_logs"][step]).split()          # 'step 0: p_loss 4.1744 v_loss 4.4605'
             assert abs(float(p_loss) - float(ref[3])) <= LOSS_TOL and abs(float(v_loss) - float(ref[5])) <= LOSS_TOL, (step, ref)

@@ -30,6 +30,7 @@ for uses, n in ((1, 512), (5, 512)):
         X, G = (torch.cat(xs), torch.cat(gs)) if uses > 1 else (xs[0], gs[0])
         return torch.ops.aten.convolution_backward(G, X, w, [128], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True])
     t_mi = timeit(miopen)
+    print("wgrad %d x %d boards, split precision: hip %.1f us" % (uses, n, timeit(lambda: CG.conv3x3_wgrad(xs, gs, dw, db, x3=True))), flush=True)
     print("wgrad %d x %d boards: hip %.1f us (%.0f TFLOP/s, %.2f TB/s of fp32 operands)   miopen (cat + wrw + bias) %.1f us" %
           (uses, n, t_hip, flop / t_hip / 1e6, uses * n * 65536 / t_hip / 1e6, t_mi), flush=True)
 
@@ -41,5 +42,7 @@ for n in (512, 2560):
     flop = 2.0 * n * 64 * 128 * 128 * 9
     t_hip = timeit(lambda: CG.conv3x3(x, pf, b, out=y))
     t_mi = timeit(lambda: torch.nn.functional.conv2d(x, w, b, padding=1))
+    pf4 = CG.pack_conv(w, split=True)
+    print("conv %d boards, split precision (3 launches): hip %.1f us" % (n, timeit(lambda: CG.conv3x3(x, pf4[0], b, out=y, packed_lo=pf4[2]))), flush=True)
     print("conv %d boards: hip %.1f us (%.0f TFLOP/s)   miopen fp32 %.1f us" % (n, t_hip, flop / t_hip / 1e6, t_mi), flush=True)
 print("pack: %.1f us" % timeit(lambda: CG.pack_conv(w)))

@@ -49,6 +49,7 @@ run("fp32 NCHW, batched, HIP bf16 convolution gradients", hip=True)
 run("fp32 NCHW, plain loss (r02), again", batched=False)
 run("fp32 NCHW, batched, again")
 run("fp32 NCHW, batched, HIP bf16 convolution gradients, again", hip=True)
+run("fp32 NCHW, batched, HIP split-precision (bf16x3) convolutions", hip="x3")
 if len(sys.argv) > 3 and sys.argv[3] == "short":
     sys.exit(0)
 run("fp32 NCHW, MIOpen find (benchmark=True)", benchmark=True)

@@ -70,6 +70,8 @@ def run(name, benchmark, amp, graph, hip=False):
 
 for graph in (False, True):
     run("fp32 + HIP bf16 tower convolutions, %s" % ("hipGraph" if graph else "eager"), False, None, graph, hip=True)
+for graph in (False, True):
+    run("fp32 + HIP split-precision (bf16x3) tower convolutions, %s" % ("hipGraph" if graph else "eager"), False, None, graph, hip="x3")
 if len(sys.argv) > 3 and sys.argv[3] == "hip":
     sys.exit(0)
 for amp in (None, torch.bfloat16):
