@@ -1,9 +1,10 @@
 """The whole MuZero loop on one GPU, end to end: G generations of (self-play -> replay window -> training -> publish),
 then the arena: trained network vs the initial one.
-python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax]
+python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax] [fp32|hip|hip_x3] [graph]
 Without lr/weight_decay the optimiser is the reference's (main.py:206: lr 1e-3, weight_decay 0.1 -- it hardly learns in
 a short run); give both to see the loop learn.  negamax = 1 sets config.negamax_value (non-default: the search maximises
-the mover's own value instead of the reference's child-mover value)."""
+the mover's own value instead of the reference's child-mover value).  hip / hip_x3: the training step's tower convolutions on
+the hand-written kernels (bf16 / split precision); graph = 1: the step replayed as one hipGraph."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +20,10 @@ config.num_unroll_steps = 5
 if len(sys.argv) > 6 and int(sys.argv[6]):
     config.negamax_value = True
     print("config.negamax_value = True")
-lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512)
+convs = sys.argv[7] if len(sys.argv) > 7 else "fp32"
+graph = len(sys.argv) > 8 and bool(int(sys.argv[8]))
+print("training convolutions: %s, step as one hipGraph: %s" % (convs, graph))
+lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512, train_convs=convs, train_graph=graph)
 init = copy.deepcopy(lp.network.state_dict())
 if len(sys.argv) > 5:
     lp.optimizer = torch.optim.SGD(lp.network.parameters(), lr=float(sys.argv[4]), momentum=config.momentum, weight_decay=float(sys.argv[5]))
