@@ -272,71 +272,80 @@ def bench_train(args, device, rec):
         T.update_weights(opt, net, rb.sample_batch(K), bucket, amp_dtype=torch.bfloat16)
     torch.cuda.synchronize()
     dt_amp = (time.perf_counter() - t0) / iters
-    # the towers' 128 -> 128 convolutions (forward, data gradient, weight gradient) on the hand-written matrix-core kernels
-    for _ in range(3 + iters):
-        if _ == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs=True)
-    torch.cuda.synchronize()
-    dt_hip = (time.perf_counter() - t0) / iters
-    # ... and that step replayed as one hipGraph (train.GraphedUpdate): the eager step is bound by the host's launches
-    gu = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs=True)
-    for _ in range(3 + iters):
-        if _ == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        gu(rb.sample_batch(K))
-    torch.cuda.synchronize()
-    dt_hipg = (time.perf_counter() - t0) / iters
-    # the same kernels in split precision (three bf16 MFMA products per fp32 product: ~1e-5 of the fp32 arithmetic), graphed
-    gu3 = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs="x3")
-    for _ in range(3 + iters):
-        if _ == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        gu3(rb.sample_batch(K))
-    torch.cuda.synchronize()
-    dt_x3 = (time.perf_counter() - t0) / iters
-    del gu, gu3
-    # the two hand-written training kernels alone, at the step's own sizes (HIP events over 30 launches each, torch's current
-    # stream = the stream they are launched on): one convolution of one use (B boards), one weight gradient over the K uses
-    from muzero_amd import convgrad as CG
-    gen = torch.Generator(device=device).manual_seed(7)
-    wconv = torch.randn(128, 128, 3, 3, device=device, generator=gen) * 0.03
-    xs = [torch.randn(B, 128, 8, 8, device=device, generator=gen).relu() for _ in range(K)]
-    gs = [torch.randn(B, 128, 8, 8, device=device, generator=gen) for _ in range(K)]
-    pf, _pb = CG.pack_conv(wconv)
-    yb, dwb, dbb = torch.empty_like(xs[0]), torch.empty_like(wconv), torch.empty(128, device=device)
-    us_conv = event_time_ms(lambda: CG.conv3x3(xs[0], pf, out=yb), 30) * 1e3
-    us_wgrad = event_time_ms(lambda: CG.conv3x3_wgrad(xs, gs, dwb, dbb), 30) * 1e3
-    conv_flop = 2.0 * B * 64 * 128 * 128 * 9
-    hip_kernels = {
-        "k_conv3x3": {"boards": B, "us_per_launch": us_conv, "tflops": conv_flop / us_conv / 1e6, "frac_of_bf16_peak": conv_flop / us_conv / 1e6 / BF16_PEAK_TFLOPS,
-                      "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board)"},
-        "k_conv_wgrad+k_wgrad_reduce": {"boards": B * K, "us_per_launch": us_wgrad, "tflops": K * conv_flop / us_wgrad / 1e6,
-                                        "frac_of_bf16_peak": K * conv_flop / us_wgrad / 1e6 / BF16_PEAK_TFLOPS,
-                                        "note": "weight + bias gradient over the K uses, fp32 NCHW operands by LDS-DMA, slice partial sums reduced in a fixed order"}}
-    del xs, gs
-    config.num_unroll_steps = 3
     # arithmetic of one step: K + 1 network passes over B boards (one Representation, K Dynamics: the same tower FLOPs), each
     # forward + gradient w.r.t. its input + gradient w.r.t. its weights = 3 x the forward FLOPs (heads and loss are < 1 %)
     flop = 3.0 * (K + 1) * B * TOWER_FLOP
-    return {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
+
+    def hip_legs():
+        # the towers' 128 -> 128 convolutions (forward, data gradient, weight gradient) on the hand-written matrix-core kernels
+        for _ in range(3 + iters):
+            if _ == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs=True)
+        torch.cuda.synchronize()
+        dt_hip = (time.perf_counter() - t0) / iters
+        # ... and that step replayed as one hipGraph (train.GraphedUpdate): the eager step is bound by the host's launches
+        gu = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs=True)
+        for _ in range(3 + iters):
+            if _ == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            gu(rb.sample_batch(K))
+        torch.cuda.synchronize()
+        dt_hipg = (time.perf_counter() - t0) / iters
+        # the same kernels in split precision (three bf16 MFMA products per fp32 product: ~1e-5 of the fp32 arithmetic), graphed
+        gu3 = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs="x3")
+        for _ in range(3 + iters):
+            if _ == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            gu3(rb.sample_batch(K))
+        torch.cuda.synchronize()
+        dt_x3 = (time.perf_counter() - t0) / iters
+        del gu, gu3
+        # the two hand-written training kernels alone, at the step's own sizes (HIP events over 30 launches each, torch's current
+        # stream = the stream they are launched on): one convolution of one use (B boards), one weight gradient over the K uses
+        from muzero_amd import convgrad as CG
+        gen = torch.Generator(device=device).manual_seed(7)
+        wconv = torch.randn(128, 128, 3, 3, device=device, generator=gen) * 0.03
+        xs = [torch.randn(B, 128, 8, 8, device=device, generator=gen).relu() for _ in range(K)]
+        gs = [torch.randn(B, 128, 8, 8, device=device, generator=gen) for _ in range(K)]
+        pf, _pb = CG.pack_conv(wconv)
+        yb, dwb, dbb = torch.empty_like(xs[0]), torch.empty_like(wconv), torch.empty(128, device=device)
+        us_conv = event_time_ms(lambda: CG.conv3x3(xs[0], pf, out=yb), 30) * 1e3
+        us_wgrad = event_time_ms(lambda: CG.conv3x3_wgrad(xs, gs, dwb, dbb), 30) * 1e3
+        conv_flop = 2.0 * B * 64 * 128 * 128 * 9
+        hip_kernels = {
+            "k_conv3x3": {"boards": B, "us_per_launch": us_conv, "tflops": conv_flop / us_conv / 1e6, "frac_of_bf16_peak": conv_flop / us_conv / 1e6 / BF16_PEAK_TFLOPS,
+                          "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board)"},
+            "k_conv_wgrad+k_wgrad_reduce": {"boards": B * K, "us_per_launch": us_wgrad, "tflops": K * conv_flop / us_wgrad / 1e6,
+                                            "frac_of_bf16_peak": K * conv_flop / us_wgrad / 1e6 / BF16_PEAK_TFLOPS,
+                                            "note": "weight + bias gradient over the K uses, fp32 NCHW operands by LDS-DMA, slice partial sums reduced in a fixed order"}}
+        del xs, gs
+        return {"hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
+                "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
+                "hip_kernels": hip_kernels, "hip_x3_graph_ms_per_step": dt_x3 * 1e3, "hip_x3_graph_samples_per_sec": B / dt_x3,
+                "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12}
+
+    try:
+        hip = hip_legs()
+    except Exception as e:   # noqa: BLE001  (optional legs: reported, not fatal to the fp32 numbers)
+        hip = {"hip_convs_error": "%s: %s" % (type(e).__name__, e)}
+    config.num_unroll_steps = 3
+    res = {"batch": B, "unroll_steps": K, "dtype": "fp32", "ms_per_step": dt * 1e3, "samples_per_sec": B / dt,
             "sample_batch_ms": ms_sample, "p_loss": float(p_loss), "v_loss": float(v_loss),
             "bf16_autocast_ms_per_step": dt_amp * 1e3, "algorithmic_flop_per_step": flop,
             "tflops": flop / dt / 1e12, "frac_of_fp32_matrix_peak": flop / dt / 1e12 / F32_PEAK_TFLOPS,
             "bf16_autocast_tflops": flop / dt_amp / 1e12, "bf16_autocast_frac_of_bf16_peak": flop / dt_amp / 1e12 / BF16_PEAK_TFLOPS,
-            "hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
-            "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
-            "hip_kernels": hip_kernels, "hip_x3_graph_ms_per_step": dt_x3 * 1e3, "hip_x3_graph_samples_per_sec": B / dt_x3,
-            "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12,
             "note": "ms_per_step: MIOpen convolutions through PyTorch autograd, fp32 as the reference; bf16_autocast: torch.autocast over the same "
                     "(fp32 master weights); hip_convs: the towers' 128 -> 128 convolutions -- forward, data gradient, weight gradient -- on the "
                     "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
                     "gradients closer to the fp32 step's than autocast's, tests/test_gpu_convgrad.py), everything else as the fp32 step; "
                     "hip_x3: those kernels in split precision (hi = bf16(v), lo = bf16(v - hi), a b = a_hi b_hi + a_lo b_hi + a_hi b_lo: a convolution "
                     "within 3e-6 of fp64, against 2e-3 for one bf16 product); *_graph: the step replayed as one hipGraph (train.GraphedUpdate)"}
+    res.update(hip)
+    return res
 
 
 def bench_loop(args, device, dtype):
@@ -606,9 +615,14 @@ def main():
             out["selfplay"] = {"games": g, "simulations": args.selfplay_sims, "moves": rec.length, "seconds": dts,
                                "games_per_sec": g / dts, "simulations_per_sec": g * rec.length * args.selfplay_sims / dts}
             if args.train_batch > 0:
-                out["train"] = bench_train(args, device, rec)
-                del sp, net_sp, rec
-                out["loop"] = bench_loop(args, device, dtype)
+                # optional legs: a failure is reported in the line, it does not take the headline with it
+                for leg, fn in (("train", lambda: bench_train(args, device, rec)), ("loop", lambda: bench_loop(args, device, dtype))):
+                    try:
+                        out[leg] = fn()
+                    except Exception as e:   # noqa: BLE001
+                        out[leg + "_error"] = "%s: %s" % (type(e).__name__, e)
+                    if leg == "train":
+                        del sp, net_sp, rec
         # ---- BASELINE configs[3] per-GPU size: 8192 trees x 100 simulations (what each of 8 GPUs runs in the sharded config)
         if args.config4_searches > 0 and getattr(net, "tower", "") == "hip":
             n4, S4 = 8192, 100
