@@ -671,6 +671,28 @@ def main():
             out["bf16_vs_fp32_search"] = dict(visit_agreement(fp32_visits, bf16_visits),
                                               note="same %d roots, same Dirichlet noise, %d simulations: bf16 HIP tower vs fp32 MIOpen inference" % (n, S))
             del eng32, net32
+            # the same fp32 search with the towers' 128 -> 128 convolutions on the hand-written kernels in split precision
+            try:
+                torch.manual_seed(1261)
+                netx = InferenceEngine(Network(), n, torch.float32, channels_last=False, tower="hip_x3")
+                engx = SelfPlayEngine(n, netx, num_simulations=S, device=device, use_graph=not args.no_graph, seed=1261 + rank)
+                engx.env = roots
+                x3_visits, _ = engx.search(image32, noise)
+                x3_visits = x3_visits.clone()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.fp32_steps):
+                    engx.search(image32, noise)
+                torch.cuda.synchronize()
+                dtx = (time.perf_counter() - t1) / args.fp32_steps
+                out["fp32_split_precision_inference"] = dict(
+                    value=n * S / dtx, unit="simulations/s", ms_per_step=dtx * 1e3, steps=args.fp32_steps,
+                    inference="fp32 serving, the towers' 128 -> 128 convolutions on k_conv3x3 in split precision (three bf16 MFMA products per fp32 "
+                              "product, fused ReLU / residual), first / last convolutions and heads through PyTorch fp32",
+                    agreement_with_fp32_search=visit_agreement(fp32_visits, x3_visits))
+                del engx, netx
+            except Exception as e:   # noqa: BLE001  (optional leg)
+                out["fp32_split_precision_inference_error"] = "%s: %s" % (type(e).__name__, e)
         else:
             fp32_visits = None
         cpu, cpu_visits = bench_cpu_baseline(args, roots, image, noise)

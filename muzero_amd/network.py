@@ -199,12 +199,16 @@ class InferenceEngine:
         # "miopen": PyTorch/MIOpen convolutions (+ the fused epilogue when fused=True).  "auto" = hip for bf16 on a GPU.
         if tower == "auto":
             tower = "hip" if (dtype == torch.bfloat16 and self.device.type == "cuda") else "miopen"
-        if tower not in ("hip", "miopen"):
-            raise ValueError("tower must be 'auto', 'hip' or 'miopen'")
+        # "hip_x3": fp32 serving with the towers' 128 -> 128 convolutions on the hand-written kernels in split precision (three
+        # bf16 MFMA products per fp32 product, muzero_amd/convgrad.py): the reference's arithmetic to ~1e-5, faster than MIOpen's fp32
+        if tower not in ("hip", "miopen", "hip_x3"):
+            raise ValueError("tower must be 'auto', 'hip', 'miopen' or 'hip_x3'")
         if tower == "hip" and dtype != torch.bfloat16:
             raise ValueError("the HIP tower serves bf16 only")
+        if tower == "hip_x3" and (dtype != torch.float32 or channels_last):
+            raise ValueError("tower='hip_x3' serves fp32 in NCHW: pass dtype=torch.float32, channels_last=False")
         self.tower = tower
-        self.fused = bool(fused and channels_last and self.device.type == "cuda")
+        self.fused = bool(fused and channels_last and self.device.type == "cuda" and tower != "hip_x3")
         if self.fused or tower == "hip":
             from . import _lib
             self._L = _lib
@@ -212,6 +216,31 @@ class InferenceEngine:
         if tower == "hip":
             self._packs = {}
             self._repack()
+        if tower == "hip_x3":
+            self._packs3 = {}
+            self._repack_x3()
+
+    # ---- split-precision tower (fp32 serving) ------------------------------------------------------
+    def _repack_x3(self):
+        """the mid convolutions' hi / lo weight images, (re)built IN PLACE (a captured hipGraph holds their addresses)"""
+        from .convgrad import PACKED_ELEMS, pack_conv
+        for name, (_first, blocks, _last, _cin) in self._tower_parts().items():
+            for bi, blk in enumerate(blocks):
+                for ci in (0, 2):
+                    key = (name, bi, ci)
+                    if key not in self._packs3:
+                        self._packs3[key] = torch.empty((4, PACKED_ELEMS), dtype=torch.bfloat16, device=self.device)
+                    pack_conv(blk.block[ci].weight.contiguous(), out=self._packs3[key], split=True)
+
+    def _tower_x3(self, name, x):
+        from .convgrad import conv3x3
+        first, blocks, last, _cin = self._tower_parts()[name]
+        y = F.relu(F.conv2d(x.contiguous(), first.weight, first.bias, 1, 1))
+        for bi, blk in enumerate(blocks):
+            p1, p2 = self._packs3[(name, bi, 0)], self._packs3[(name, bi, 2)]
+            t = conv3x3(y, p1[0], blk.block[0].bias, relu=True, packed_lo=p1[2])
+            y = conv3x3(t, p2[0], blk.block[2].bias, relu=True, skip=y, packed_lo=p2[2])   # relu(x + block(x)), network.py:46-47
+        return F.relu(F.conv2d(y, last.weight, last.bias, 1, 1))
 
     # ---- HIP tower ---------------------------------------------------------------------------------
     def _tower_parts(self):
@@ -316,6 +345,8 @@ class InferenceEngine:
             t.copy_(state_dict[k])
         if self.tower == "hip":
             self._repack()
+        if self.tower == "hip_x3":
+            self._repack_x3()
 
     # ---- fused tower: conv (MIOpen, no bias) + one epilogue pass ---------------------------------
     def _epi(self, y, bias, residual=None):
@@ -341,6 +372,8 @@ class InferenceEngine:
         r = self.net.representation
         if self.tower == "hip":
             return self._tower_hip("repr", image.contiguous())
+        if self.tower == "hip_x3":
+            return self._tower_x3("repr", image)
         image = image.contiguous(memory_format=self.mf)
         if not self.fused:
             return r(image)
@@ -350,6 +383,8 @@ class InferenceEngine:
         d = self.net.dynamics.conv
         if self.tower == "hip":
             return self._tower_hip("dyn", x10.contiguous())
+        if self.tower == "hip_x3":
+            return self._tower_x3("dyn", x10)
         x10 = x10.contiguous(memory_format=self.mf)
         if not self.fused:
             return d(x10)

@@ -222,3 +222,31 @@ def test_zero_halo_reads_past_the_lds_allocation():
     first = torch.nn.functional.conv2d(x10[:1].float(), torch.ones(1, 10, 3, 3, device="cuda"), padding=1)[0, 0]
     assert first[0, 0] == 40 and first[0, 3] == 60 and first[3, 3] == 90
     assert got[0, 0, 0, 0] < got[0, 0, 0, 3] < got[0, 0, 3, 3]
+
+
+@pytest.mark.parametrize("B", [192, 2100])   # 4-board and 8-board tiles of the convolution kernel
+def test_split_precision_engine_matches_fp32_module(B):
+    """tower="hip_x3": fp32 serving with the towers' 128 -> 128 convolutions on the hand-written kernels in split precision
+    (three bf16 MFMA products per fp32 product) against the fp32 module through PyTorch/MIOpen: two orders of magnitude
+    inside the bf16 serving tolerance, and new weights are served after load_weights"""
+    from muzero_amd.network import InferenceEngine, Network
+    torch.manual_seed(1261)
+    net = Network()
+    x3 = InferenceEngine(net, B, torch.float32, channels_last=False, tower="hip_x3")
+    ref = InferenceEngine(net, B, torch.float32, fused=False, tower="miopen")
+    img = (torch.rand(B, 9, 8, 8, device="cuda") < 0.3).float()
+    x10 = torch.rand(B, 10, 8, 8, device="cuda")
+
+    def check(tol):
+        for a, b in ((x3.initial(img), ref.initial(img)), (x3.recurrent(x10), ref.recurrent(x10))):
+            for u, v, name in zip(a, b, ("value", "policy", "hidden")):
+                assert u.shape == v.shape and u.dtype == v.dtype == torch.float32 and u.is_contiguous()
+                assert (u - v).abs().max().item() <= tol * max(1.0, v.abs().max().item()), name
+    check(1e-4)
+    torch.manual_seed(7)
+    other = Network()
+    x3.load_weights(other.state_dict())
+    ref.load_weights(other.state_dict())
+    check(1e-4)
+    with pytest.raises(ValueError):
+        InferenceEngine(net, B, torch.bfloat16, tower="hip_x3")
