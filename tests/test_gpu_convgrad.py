@@ -141,7 +141,7 @@ def test_conv3x3_on_fp32_values_is_within_bf16_rounding():
     assert (y.double() - ref).norm().item() <= 4e-3 * ref.norm().item()
 
 
-@pytest.mark.parametrize("hip", [False, True])
+@pytest.mark.parametrize("hip", [False, True, "x3"])
 def test_graphed_update_equals_eager_steps(hip):
     """train.GraphedUpdate: the captured step replayed on fresh batches follows the eager steps (same kernels; MIOpen's own
     weight-gradient kernels for the first / last convolutions are not bit-reproducible, hence a tolerance), and building it
