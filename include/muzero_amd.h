@@ -474,6 +474,8 @@ int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, int3
  *       y  = conv(x hi, W hi) + bias [+ residual skip];   y += conv(x lo, W hi);   y = epilogue(y + conv(x hi, W lo))
  *   mz_conv3x3_wgrad_x3 forms the three products inside one pass over the operands. */
 int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream);
+/* the same for up to 16 convolutions in ONE launch (a training step repacks all twelve): w, packed_fwd, packed_bwd are HOST arrays of n pointers */
+int mz_conv3x3_pack_many(const float *const *w, void *const *packed_fwd, void *const *packed_bwd, int32_t n, int32_t part, void *stream);
 int mz_conv3x3_wgrad_x3(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
                         int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
 

@@ -110,6 +110,7 @@ SIGNATURES = {
     "mz_conv3x3_forward": [_p, _p, _p, _p, _i64, _i32, _p],
     "mz_conv3x3_fused": [_p, _p, _p, _i32, _p, _p, _p, _i64, _i32, _p],
     "mz_conv3x3_pack_part": [_p, _p, _p, _i32, _p],
+    "mz_conv3x3_pack_many": [_p, _p, _p, _i32, _i32, _p],
     "mz_conv3x3_wgrad_x3": [_p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p],
 }
 for _name, _args in SIGNATURES.items():

@@ -73,6 +73,24 @@ def pack_conv(weight, out=None, split=False):
     return out[0], out[1], out[2], out[3]
 
 
+def pack_convs(weights, split=False):
+    """pack_conv for up to 16 weights in one launch (two with split=True): a list of pack_conv's result tuples"""
+    ws = [w.detach() for w in weights]
+    if not 1 <= len(ws) <= 16:
+        raise L.MzError("pack_convs: 1..16 weights")
+    for w in ws:
+        if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
+            raise L.MzError("pack_convs: need contiguous cuda float32 (128,128,3,3) weights")
+    k = len(ws)
+    out = torch.empty((k, 4 if split else 2, PACKED_ELEMS), dtype=torch.bfloat16, device=ws[0].device)
+    wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
+    for part in ((0, 1) if split else (0,)):
+        fp = (C.c_void_p * k)(*[out[i, 2 * part].data_ptr() for i in range(k)])
+        bp = (C.c_void_p * k)(*[out[i, 2 * part + 1].data_ptr() for i in range(k)])
+        L.call("mz_conv3x3_pack_many", wp, fp, bp, k, part, L.current_stream())
+    return [tuple(out[i, j] for j in range(out.shape[1])) for i in range(k)]
+
+
 def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, packed_lo=None):
     """y = [relu]( [mask > 0 ?] (conv3x3(x) + bias [+ skip]) : 0 ) with the packed weight image (forward image: the convolution;
     data-gradient image applied to a grad_output: the input gradient).  x, skip, mask (n,128,8,8) f32 NCHW (mz_conv3x3_fused).

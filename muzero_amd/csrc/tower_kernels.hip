@@ -950,35 +950,52 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
 //   forward : stage (ky*3+kx)*4 + ci/32, row co, element = W[co][ci][ky][kx]
 //   backward: stage (ky*3+kx)*4 + co/32, row ci, element = W[co][ci][2-ky][2-kx]   (the data gradient as a convolution of g)
 // slot s of a row holds the 8-channel chunk s ^ {0,2,3,1}[(row >> 2) & 3]; the 4 trailing stages are zero (prefetch padding)
-__global__ void __launch_bounds__(256) k_conv3x3_pack(const float *__restrict__ wsrc, uint16_t *__restrict__ fwd, uint16_t *__restrict__ bwd, int part) {
+constexpr int PACK_MANY = 16;
+struct PackArgs { const float *w[PACK_MANY]; uint16_t *fwd[PACK_MANY]; uint16_t *bwd[PACK_MANY]; int part; };
+
+__global__ void __launch_bounds__(256) k_conv3x3_pack(PackArgs a) {   // blockIdx.y = which convolution
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (stage, row, slot, e)
     if (idx >= 40 * 4096) return;
+    const float *__restrict__ wsrc = a.w[blockIdx.y];
     const int e = idx & 7, slot = (idx >> 3) & 3, row = (idx >> 5) & 127, stage = idx >> 12;
     uint16_t f = 0, bk = 0;
     if (stage < 36) {
         const int tap = stage >> 2, quarter = stage & 3, ky = tap / 3, kx = tap % 3;
         const int ch = quarter * 32 + ((slot ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3) + e;
         float wf = wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx], wb = wsrc[((ch * 128 + row) * 3 + (2 - ky)) * 3 + (2 - kx)];
-        if (part) {   // the rounding remainder w - bf16(w): exact in f32, then rounded to bf16 itself
+        if (a.part) {   // the rounding remainder w - bf16(w): exact in f32, then rounded to bf16 itself
             wf -= bf16_up(bf16_rne(wf));
             wb -= bf16_up(bf16_rne(wb));
         }
         f = (uint16_t)bf16_rne(wf);
         bk = (uint16_t)bf16_rne(wb);
     }
-    fwd[idx] = f;
-    bwd[idx] = bk;
+    a.fwd[blockIdx.y][idx] = f;
+    a.bwd[blockIdx.y][idx] = bk;
 }
 
 }  // namespace
 
-extern "C" int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream) {
+extern "C" int mz_conv3x3_pack_many(const float *const *w, void *const *packed_fwd, void *const *packed_bwd, int32_t n, int32_t part, void *stream) {
     MZ_REQUIRE(w && packed_fwd && packed_bwd, "mz_conv3x3_pack: null pointer");
-    MZ_REQUIRE((((uintptr_t)packed_fwd | (uintptr_t)packed_bwd) & 15) == 0, "mz_conv3x3_pack: outputs must be 16-byte aligned");
+    MZ_REQUIRE(n >= 1 && n <= PACK_MANY, "mz_conv3x3_pack_many: %d convolutions outside [1, %d]", n, PACK_MANY);
     MZ_REQUIRE(part == 0 || part == 1, "mz_conv3x3_pack: part must be 0 (the bf16 rounding) or 1 (its remainder)");
-    hipLaunchKernelGGL(k_conv3x3_pack, dim3(40 * 4096 / 256), dim3(256), 0, (hipStream_t)stream, w, (uint16_t *)packed_fwd, (uint16_t *)packed_bwd, (int)part);
+    PackArgs a{};
+    for (int i = 0; i < n; ++i) {
+        MZ_REQUIRE(w[i] && packed_fwd[i] && packed_bwd[i], "mz_conv3x3_pack: null pointer (convolution %d)", i);
+        MZ_REQUIRE((((uintptr_t)packed_fwd[i] | (uintptr_t)packed_bwd[i]) & 15) == 0, "mz_conv3x3_pack: outputs must be 16-byte aligned");
+        a.w[i] = w[i];
+        a.fwd[i] = (uint16_t *)packed_fwd[i];
+        a.bwd[i] = (uint16_t *)packed_bwd[i];
+    }
+    a.part = (int)part;
+    hipLaunchKernelGGL(k_conv3x3_pack, dim3(40 * 4096 / 256, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_conv3x3_pack");
     return MZ_OK;
+}
+
+extern "C" int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream) {
+    return mz_conv3x3_pack_many(&w, &packed_fwd, &packed_bwd, 1, part, stream);
 }
 
 extern "C" int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream) {

@@ -160,6 +160,14 @@ class DeferredWeightGrads:
             packed = self.packed[id(conv)] = pack_conv(conv.weight, split=self.x3)
         return packed
 
+    def prepack(self, convs):
+        """the packed images of all the step's tower convolutions in ONE launch (two in split precision)"""
+        convs = [c for c in convs if id(c) not in self.packed]
+        if self.hip and convs and convs[0].weight.is_cuda:
+            from .convgrad import pack_convs
+            for c, p in zip(convs, pack_convs([c.weight for c in convs], split=self.x3)):
+                self.packed[id(c)] = p
+
     def park(self, conv, x, g):
         self.sinks.setdefault(id(conv), (conv, []))[1].append((x, g))
 
@@ -266,6 +274,9 @@ def muzero_loss_batched(network, batch, dw):
     (call dw.flush() after backward).  Returns (p_loss, v_loss)."""
     dev = next(network.parameters()).device
     image, actions, target_values, target_policies = (torch.as_tensor(x, dtype=torch.float32).to(dev) for x in batch)
+    if dw.hip and image.is_cuda:
+        dw.prepack([c for blk in list(network.representation.conv2) + [network.dynamics.conv[i] for i in (2, 3, 4)] for c in (blk.block[0], blk.block[2])
+                    if c.in_channels == 128 and c.out_channels == 128])
     hidden = _representation_deferred(network.representation, image, dw) if dw.hip else network.representation(image)
     hiddens = [hidden]
     for action in actions:

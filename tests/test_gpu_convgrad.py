@@ -244,3 +244,15 @@ def test_training_gradients_in_split_precision_match_the_fp32_step():
     rel = sorted(float((got[k].double() - ref[k].double()).norm() / ref[k].double().norm().clamp_min(1e-12)) for k in ref)
     print("split precision vs fp32: per-tensor relative L2 worst %.3g median %.3g" % (rel[-1], rel[len(rel) // 2]))
     assert rel[-1] <= 5e-3 and rel[len(rel) // 2] <= 5e-4
+
+
+def test_pack_convs_equals_pack_conv():
+    from muzero_amd.convgrad import pack_conv, pack_convs
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ws = [torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03 for _ in range(12)]
+    for split in (False, True):
+        many = pack_convs(ws, split=split)
+        assert len(many) == 12
+        for w, got in zip(ws, many):
+            want = pack_conv(w, split=split)
+            assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
