@@ -31,6 +31,9 @@ def test_wgrad_matches_fp64_convolution_backward_on_bf16_values(boards):
     # products of bf16 values are exact in fp32; what differs from the fp64 sum is fp32 accumulation over n * 64 terms
     assert (dw.double() - gw).abs().max().item() <= 2e-5 * gw.abs().max().item() + 1e-6
     assert (db.double() - gb).abs().max().item() <= 2e-5 * gb.abs().max().item() + 1e-6
+    dw0 = torch.empty_like(dw)
+    conv3x3_wgrad(xs, gs, dw0)                      # a convolution without bias: no db
+    assert torch.equal(dw0, dw)
     # accumulate: adds to what the outputs hold; deterministic: the same bits again
     dw2, db2 = dw.clone(), db.clone()
     conv3x3_wgrad(xs, gs, dw2, db2, accumulate=True)
