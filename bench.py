@@ -318,10 +318,14 @@ def bench_train(args, device, rec):
         conv_flop = 2.0 * B * 64 * 128 * 128 * 9
         hip_kernels = {
             "k_conv3x3": {"boards": B, "us_per_launch": us_conv, "tflops": conv_flop / us_conv / 1e6, "frac_of_bf16_peak": conv_flop / us_conv / 1e6 / BF16_PEAK_TFLOPS,
-                          "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board)"},
+                          "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "frac_of_hbm_peak": B * 65536 / us_conv / 1e3 / HBM_PEAK_GBPS,
+                          "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board = 295 FLOP/B: as HBM-bound as "
+                                  "MFMA-bound); at this batch 128 workgroups of 4 boards, one tile each: load, K loop and store phases do not overlap"},
             "k_conv_wgrad+k_wgrad_reduce": {"boards": B * K, "us_per_launch": us_wgrad, "tflops": K * conv_flop / us_wgrad / 1e6,
                                             "frac_of_bf16_peak": K * conv_flop / us_wgrad / 1e6 / BF16_PEAK_TFLOPS,
-                                            "note": "weight + bias gradient over the K uses, fp32 NCHW operands by LDS-DMA, slice partial sums reduced in a fixed order"}}
+                                            "hbm_gbps_fp32_operands": B * K * 98304 / us_wgrad / 1e3, "frac_of_hbm_peak": B * K * 98304 / us_wgrad / 1e3 / HBM_PEAK_GBPS,
+                                            "note": "weight + bias gradient over the K uses, fp32 NCHW operands by LDS-DMA (each co-half workgroup pulls 48 KB per "
+                                                    "board: 197 FLOP/B, HBM-bound), slice partial sums (75 MB written and re-read) reduced in a fixed order"}}
         del xs, gs
         return {"hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
                 "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
