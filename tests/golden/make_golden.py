@@ -3,7 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk [n_games]    (verdict only, ~25 min on 8 cores)
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows] | bulk_arena [n_games] | bulk_train [n_runs]    (verdicts only)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows] | bulk_arena [n_games] | bulk_train [n_runs] | checkpoint_xload    (verdicts only)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -1112,10 +1112,66 @@ def gen_bulk_train(n_runs=24):
     assert tot["batched_median_grad_rel_l2"] <= 1e-6 and tot["batched_worst_grad_rel_l2"] <= 2e-2 and tot["loss_worst_abs"] <= 1e-4
 
 
+# ------------------------------------------------------------------------------------------------
+# checkpoints (main.py:223-224, test.py:247-250): cross-loading with the reference, verdict only
+# ------------------------------------------------------------------------------------------------
+def gen_checkpoint_xload(n=8):
+    """(a) a file written the reference's way (torch.save(network.state_dict()), main.py:224) from the
+    IMPORTED reference Network loads through muzero_amd.train.load_checkpoint; (b) a file written by
+    muzero_amd.train.save_checkpoint loads the reference's way (Network().load_state_dict(torch.load(...)), test.py:247-250);
+    after either, the two networks' initial_inference / recurrent_inference agree BIT FOR BIT on random inputs (CPU, fp32).
+    Verdict only: tests/golden/checkpoint_xload_verdict.json."""
+    import json
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    tot = dict(cases=0, reference_file_loaded_by_build=0, build_file_loaded_by_reference=0, outputs_compared=0, outputs_not_bit_equal=0)
+
+    def same(a_net, b_net, seed):
+        g = torch.Generator().manual_seed(seed)
+        img = (torch.rand(3, 9, 8, 8, generator=g) < 0.3).float()
+        act = (torch.rand(3, 2, 8, 8, generator=g) < 0.1).float()
+        bad = 0
+        with torch.no_grad():
+            a, b = a_net.initial_inference(img), b_net.initial_inference(img)
+            a2, b2 = a_net.recurrent_inference(a[2], act), b_net.recurrent_inference(b[2], act)
+        for u, v in zip(tuple(a) + tuple(a2), tuple(b) + tuple(b2)):
+            tot["outputs_compared"] += 1
+            bad += int(not torch.equal(u, v))
+        tot["outputs_not_bit_equal"] += bad
+        return bad == 0
+
+    with tempfile.TemporaryDirectory() as d:
+        for i in range(n):
+            torch.manual_seed(100 + i)
+            ref = M.Network()
+            path = os.path.join(d, "%dmodel.pth" % (1000 * (i + 1)))
+            torch.save(ref.state_dict(), path)                                   # main.py:224
+            mine = T.load_checkpoint(Network(), path)
+            tot["reference_file_loaded_by_build"] += int(same(ref.eval(), mine.eval(), i))
+            torch.manual_seed(200 + i)
+            mine2 = Network()
+            path2 = T.save_checkpoint(mine2, 1000 * (i + 1), os.path.join(d, "models"))
+            ref2 = M.Network()
+            ref2.load_state_dict(torch.load(path2, map_location="cpu"))           # test.py:247 (a file this build wrote)
+            tot["build_file_loaded_by_reference"] += int(same(ref2.eval(), mine2.eval(), 50 + i))
+            tot["cases"] += 1
+    tot.update(reference="/root/reference main.Network + torch.save / load_state_dict as main.py:224 and test.py:247-250 use them, imported in the build container",
+               compared="value, policy, hidden of initial_inference and recurrent_inference on random inputs, torch.equal")
+    with open(os.path.join(HERE, "checkpoint_xload_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["outputs_not_bit_equal"] == 0 and tot["reference_file_loaded_by_build"] == tot["build_file_loaded_by_reference"] == n
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "bulk":
         gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
+    if what == "checkpoint_xload":
+        gen_checkpoint_xload()
         sys.exit(0)
     if what == "bulk_train":
         gen_bulk_train(int(sys.argv[2]) if len(sys.argv) > 2 else 24)

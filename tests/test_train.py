@@ -222,3 +222,14 @@ def test_bulk_reference_verdict_is_committed_and_clean(golden_dir):
     assert v["plain_bit_equal_tensors"] == v["plain_bit_equal_gradients"] == v["tensors"] and v["plain_worst_rel"] == 0.0
     assert v["batched_median_grad_rel_l2"] <= 1e-6 and v["batched_p99_grad_rel_l2"] <= 1e-4 and v["batched_worst_grad_rel_l2"] <= 2e-2
     assert v["loss_worst_abs"] <= 1e-4   # the reference prints 4 decimals
+
+
+def test_checkpoint_cross_loading_verdict_is_committed_and_clean(golden_dir):
+    """files written the reference's way by the IMPORTED reference load through load_checkpoint, files
+    written by save_checkpoint load the reference's way into the reference's Network, and after either both networks'
+    initial_inference / recurrent_inference agree bit for bit (tests/golden/make_golden.py checkpoint_xload, build container
+    only; only the verdict travels)"""
+    import json
+    v = json.load(open(os.path.join(golden_dir, "checkpoint_xload_verdict.json")))
+    assert v["cases"] >= 8 and v["reference_file_loaded_by_build"] == v["build_file_loaded_by_reference"] == v["cases"]
+    assert v["outputs_compared"] == 12 * v["cases"] and v["outputs_not_bit_equal"] == 0
