@@ -3,7 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [env|mcts|features|game|replay|arena|all]
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk [n_games]    (verdict only, ~25 min on 8 cores)
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows] | bulk_arena [n_games] | bulk_train [n_runs] | checkpoint_xload    (verdicts only)
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py bulk_mcts [n] | bulk_replay [n_windows] | bulk_arena [n_games] | bulk_train [n_runs] | bulk_games [n] | checkpoint_xload    (verdicts only)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; what travels are
 the small ``.npz`` files this script writes next to itself (inputs + expected outputs only).
@@ -1165,10 +1165,97 @@ def gen_checkpoint_xload(n=8):
     assert tot["outputs_not_bit_equal"] == 0 and tot["reference_file_loaded_by_build"] == tot["build_file_loaded_by_reference"] == n
 
 
+# ------------------------------------------------------------------------------------------------
+# bulk verdict for WHOLE GAMES (main.play_game, main.py:69-92): reference self-play vs the oracle, verdict only
+# ------------------------------------------------------------------------------------------------
+def _bulk_game_chunk(job):
+    """one game of the IMPORTED reference's play_game on a HashNet (mode by job), np.random draws recorded as in gen_game, then
+    the oracle's play_game_hashnet on the recorded noise / uniforms: actions, rewards, visit distributions, root value bits"""
+    from oracle import mz_oracle as O
+    modes = ("hash", "sat", "const", "uniform")
+    mode, S = modes[job % 4], (6, 16, 30, 50)[(job // 4) % 4]
+    orig_legal = M.Game.legal_actions
+    M.Game.legal_actions = lambda self: sorted(self.environment.legal_actions, key=lambda a: a.index)
+    orig_dir, orig_choice = np.random.dirichlet, np.random.choice
+    M.config.num_simulations = S
+    np.random.seed(9000 + job)
+    noises, us = [], []
+
+    def rec_dirichlet(alpha, *a, **k):
+        d = orig_dir(alpha, *a, **k)
+        noises.append(np.array(d))
+        return d
+
+    def rec_choice(actions, p=None):
+        st = np.random.get_state()
+        r = orig_choice(actions, p=p)
+        rs = np.random.RandomState()
+        rs.set_state(st)
+        us.append(rs.random_sample())
+        return r
+
+    np.random.dirichlet, np.random.choice = rec_dirichlet, rec_choice
+    try:
+        game = M.play_game(HashNetwork(mode))
+    finally:
+        np.random.dirichlet, np.random.choice = orig_dir, orig_choice
+        M.Game.legal_actions = orig_legal
+        M.config.num_simulations = 60
+    n = len(game.action_history)
+    g2 = M.Game()
+    noise = np.zeros((n, 65), np.float64)
+    for t in range(n):
+        legal = sorted(a.index for a in g2.environment.legal_actions)
+        noise[t, legal] = noises[t]
+        g2.apply(M.Action(game.action_history[t].index, g2.to_play()))
+    u = np.zeros(n, np.float64)
+    u[:len(us)] = us
+    on, oact, orew, ovis, orv, _, _ = O.play_game_hashnet(S, R.MODES[mode], noise, u)
+    acts = np.array([a.index for a in game.action_history], np.uint8)
+    same_len = on == n
+    cv = np.stack([O.child_visits(v) for v in ovis[:n]]) if same_len else None
+    return dict(games=1, moves=n,
+                mismatched_actions=int(not same_len or not (oact[:n] == acts).all()),
+                mismatched_rewards=int(not same_len or not (orew[:n] == np.array(game.rewards, np.int8)).all()),
+                mismatched_child_visits=int(not same_len or not (cv == np.array(game.child_visits, np.float64)).all()),
+                mismatched_root_value_bits=int(not same_len or orv[:n].view(np.uint32).tolist() !=
+                                               np.array([float(v) for v in game.root_values], np.float32).view(np.uint32).tolist()),
+                passes=int((acts == 64).sum()), done=int(game.terminal()), sampled_moves=len(us))
+
+
+def gen_bulk_games(n_games=256):
+    """whole reference self-play games (main.play_game: per move expand_node + add_exploration_noise + run_mcts + select_action
+    + store_search_statistics, main.py:69-92) on HashNets of 4 modes at 6 / 16 / 30 / 50 simulations, against
+    oracle/mz_oracle.c's play_game_hashnet fed the recorded noise and uniforms.  Verdict only."""
+    import json
+    import multiprocessing as mp
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    t0 = time.time()
+    tot = {}
+    with mp.Pool(8) as pool:
+        for k, st in enumerate(pool.imap_unordered(_bulk_game_chunk, range(n_games))):
+            for key, v in st.items():
+                tot[key] = tot.get(key, 0) + int(v)
+            if k % 16 == 0:
+                print("bulk_games: %d games, %.0f s" % (tot["games"], time.time() - t0), flush=True)
+    tot["mismatches"] = tot["mismatched_actions"] + tot["mismatched_rewards"] + tot["mismatched_child_visits"] + tot["mismatched_root_value_bits"]
+    tot.update(simulations=[6, 16, 30, 50], modes=["hash", "sat", "const", "uniform"], seconds=round(time.time() - t0, 1), processes=8,
+               reference="/root/reference/main.py play_game imported in the build container (legal list sorted by index, np.random draws recorded)",
+               compared="every move, reward, child_visits row (float64) and root value (float32 bits) of every game vs oracle/mz_oracle.c play_game_hashnet")
+    with open(os.path.join(HERE, "bulk_games_verdict.json"), "w") as f:
+        json.dump(tot, f, indent=1)
+    print(json.dumps(tot))
+    assert tot["mismatches"] == 0
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "bulk":
         gen_bulk(int(sys.argv[2]) if len(sys.argv) > 2 else 131072)
+        sys.exit(0)
+    if what == "bulk_games":
+        gen_bulk_games(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
         sys.exit(0)
     if what == "checkpoint_xload":
         gen_checkpoint_xload()

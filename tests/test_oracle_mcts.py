@@ -170,3 +170,15 @@ def test_bulk_reference_search_verdict_is_committed_and_clean(golden_dir):
     assert set(v["by_S"]) == {"50", "60", "100", "200"} and set(v["by_mode"]) == {"hash", "sat", "const", "uniform"}
     assert {"None", "(-1, 1)", "(-0.25, 0.3)"} <= set(v["by_bounds"]) and {"0.9", "0.997", "1.0"} <= set(v["by_discount"])
     assert min(v["by_noise"].values()) >= 2000 and len(v["by_moves_decile"]) == 6
+
+
+def test_bulk_reference_games_verdict_is_committed_and_clean(golden_dir):
+    """whole self-play games of the IMPORTED reference (main.play_game, main.py:69-92: root expansion, Dirichlet noise, run_mcts,
+    select_action with its t = 1 / t = 0 switch at move 20, store_search_statistics; tests/golden/make_golden.py bulk_games, build
+    container only) on HashNets of 4 modes at 6 / 16 / 30 / 50 simulations against this oracle's play_game_hashnet on the recorded
+    noise and uniforms: every move, reward, child_visits row and root value.  Only the verdict travels."""
+    import json
+    v = json.load(open(os.path.join(golden_dir, "bulk_games_verdict.json")))
+    assert v["games"] >= 2000 and v["moves"] == 60 * v["games"]
+    assert v["mismatches"] == v["mismatched_actions"] == v["mismatched_rewards"] == v["mismatched_child_visits"] == v["mismatched_root_value_bits"] == 0
+    assert v["passes"] > 100 and 0 < v["done"] < v["games"] and v["sampled_moves"] == 20 * v["games"]
