@@ -285,25 +285,14 @@ def bench_train(args, device, rec):
             T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs=True)
         torch.cuda.synchronize()
         dt_hip = (time.perf_counter() - t0) / iters
-        # ... and that step replayed as one hipGraph (train.GraphedUpdate): the eager step is bound by the host's launches
-        gu = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs=True)
+        # the same kernels in split precision (three bf16 MFMA products per fp32 product: ~1e-5 of the fp32 arithmetic)
         for _ in range(3 + iters):
             if _ == 3:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            gu(rb.sample_batch(K))
-        torch.cuda.synchronize()
-        dt_hipg = (time.perf_counter() - t0) / iters
-        # the same kernels in split precision (three bf16 MFMA products per fp32 product: ~1e-5 of the fp32 arithmetic), graphed
-        gu3 = T.GraphedUpdate(opt, net, bucket, rb.sample_batch(K), hip_convs="x3")
-        for _ in range(3 + iters):
-            if _ == 3:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            gu3(rb.sample_batch(K))
+            T.update_weights(opt, net, rb.sample_batch(K), bucket, hip_convs="x3")
         torch.cuda.synchronize()
         dt_x3 = (time.perf_counter() - t0) / iters
-        del gu, gu3
         # the two hand-written training kernels alone, at the step's own sizes (HIP events over 30 launches each, torch's current
         # stream = the stream they are launched on): one convolution of one use (B boards), one weight gradient over the K uses
         from muzero_amd import convgrad as CG
@@ -329,8 +318,7 @@ def bench_train(args, device, rec):
         del xs, gs
         return {"hip_convs_ms_per_step": dt_hip * 1e3, "hip_convs_samples_per_sec": B / dt_hip, "hip_convs_tflops": flop / dt_hip / 1e12,
                 "hip_convs_frac_of_bf16_peak": flop / dt_hip / 1e12 / BF16_PEAK_TFLOPS,
-                "hip_kernels": hip_kernels, "hip_x3_graph_ms_per_step": dt_x3 * 1e3, "hip_x3_graph_samples_per_sec": B / dt_x3,
-                "hip_convs_graph_ms_per_step": dt_hipg * 1e3, "hip_convs_graph_samples_per_sec": B / dt_hipg, "hip_convs_graph_tflops": flop / dt_hipg / 1e12}
+                "hip_kernels": hip_kernels, "hip_x3_ms_per_step": dt_x3 * 1e3, "hip_x3_samples_per_sec": B / dt_x3}
 
     try:
         hip = hip_legs()
@@ -347,7 +335,8 @@ def bench_train(args, device, rec):
                     "hand-written HIP kernels (mz_conv3x3_forward / mz_conv3x3_wgrad: bf16 operands, fp32 sums, fp32 master weights; "
                     "gradients closer to the fp32 step's than autocast's, tests/test_gpu_convgrad.py), everything else as the fp32 step; "
                     "hip_x3: those kernels in split precision (hi = bf16(v), lo = bf16(v - hi), a b = a_hi b_hi + a_lo b_hi + a_hi b_lo: a convolution "
-                    "within 3e-6 of fp64, against 2e-3 for one bf16 product); *_graph: the step replayed as one hipGraph (train.GraphedUpdate)"}
+                    "within 3e-6 of fp64, against 2e-3 for one bf16 product).  All steps eager: the step replayed as one hipGraph is 4.1 ms but is not "
+                    "shipped -- replays intermittently compute a wrong gradient on this stack, with or without these kernels (DESIGN.md 5)"}
     res.update(hip)
     return res
 
@@ -379,7 +368,6 @@ def bench_loop(args, device, dtype):
     dto = time.perf_counter() - t0
     # and with the training steps' tower convolutions on the HIP kernels (train_convs="hip")
     lp.hip_convs = True
-    lp.train_graph = True                 # the training step replayed as one hipGraph (train.GraphedUpdate)
     lp.generation(2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -396,7 +384,7 @@ def bench_loop(args, device, dtype):
     return {"games": g, "simulations": args.selfplay_sims, "train_steps": steps, "batch": args.train_batch,
             "unroll_steps": args.train_unroll, "seconds_per_generation": dt, "games_per_sec": g / dt,
             "overlapped_seconds_per_generation": dto, "overlapped_games_per_sec": g / dto,
-            "hip_convs_note": "train_convs=hip, train_graph=True", "hip_convs_seconds_per_generation": dth, "hip_convs_games_per_sec": g / dth,
+            "hip_convs_note": "train_convs=hip", "hip_convs_seconds_per_generation": dth, "hip_convs_games_per_sec": g / dth,
             "hip_convs_overlapped_seconds_per_generation": dtho, "hip_convs_overlapped_games_per_sec": g / dtho,
             "p_loss": float(losses[-1][0]), "v_loss": float(losses[-1][1])}
 

@@ -13,7 +13,7 @@ _workspaces = {}
 
 def _workspace(device, nbytes):
     """the weight gradient's partial-sum scratch: ONE buffer per device, allocated once at the size the largest call needs
-    (the slice count is capped, so that is 75.6 MB) and never replaced -- a captured hipGraph (train.GraphedUpdate) holds its
+    (the slice count is capped, so that is 75.6 MB) and never replaced -- a caller's captured hipGraph may hold its
     address.  Calls on one device share it: weight-gradient calls that overlap in time on two streams would race."""
     ws = _workspaces.get(device)
     if ws is None:

@@ -37,15 +37,14 @@ from . import train as T
 
 class MuZeroLoop:
     def __init__(self, games_per_rank, device="cuda", infer_dtype=torch.bfloat16, num_simulations=None, window_size=None,
-                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated", train_convs="fp32", train_graph=False):
+                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated", train_convs="fp32"):
         """replay_mode "replicated": trajectories are all_gathered and every rank holds the whole window (what
         BASELINE configs[3] describes); "sharded": no gather at all -- every rank keeps only the games it played (1/N of the
         window), all ranks make the same global draws and each trains on the draws that hit its own games, with the
         gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw.
         train_convs "fp32": the reference's arithmetic (PyTorch/MIOpen); "hip": the towers' 128 -> 128 convolutions and their
         gradients on the hand-written matrix-core kernels (bf16 operands, fp32 sums and master weights: train.update_weights
-        hip_convs); "hip_x3": those kernels in split precision (three bf16 products per fp32 product: close to fp32).  train_graph: the training step replayed as one hipGraph (train.GraphedUpdate; one process, replicated
-        window only -- the captured step holds no collective)."""
+        hip_convs); "hip_x3": those kernels in split precision (three bf16 products per fp32 product: close to fp32)."""
         self.group = group
         self.world = dist.get_world_size(group) if T._dist_on(group) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -69,10 +68,6 @@ class MuZeroLoop:
         if train_convs not in ("fp32", "hip", "hip_x3"):
             raise ValueError("train_convs must be 'fp32', 'hip' or 'hip_x3'")
         self.hip_convs = {"fp32": False, "hip": True, "hip_x3": "x3"}[train_convs]
-        if train_graph and (self.world > 1 or replay_mode != "replicated"):
-            raise ValueError("train_graph needs one process and the replicated window")
-        self.train_graph = bool(train_graph)
-        self._graphed = None
         self.games_per_rank = int(games_per_rank)
         window = int(window_size if window_size is not None else config.window_size)
         if replay_mode == "sharded":
@@ -103,11 +98,6 @@ class MuZeroLoop:
             pos = [self.replay.sample_position(i) for i in idx]                    # utilities.py:78
             sl = slice(self.rank * shard, (self.rank + 1) * shard)
             batch, scale = self.replay.sample_batch(K, idx[sl], pos[sl]), 1.0
-            if self.train_graph:
-                if self._graphed is None or self._graphed_hip != self.hip_convs:
-                    self._graphed = T.GraphedUpdate(self.optimizer, self.network, self.bucket, batch, hip_convs=self.hip_convs)
-                    self._graphed_hip = self.hip_convs
-                return self._graphed(batch)
         else:
             # every game of this engine lasts exactly max_moves moves (selfplay.py), so all ranks can make the
             # reference's position draw (utilities.py:104) for games they do not hold

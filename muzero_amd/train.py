@@ -342,59 +342,6 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
     return p_loss.detach(), v_loss.detach()
 
 
-class GraphedUpdate:
-    """update_weights (zero the gradients, K + 1 network passes, backward, weight-gradient flush, optimiser step) captured ONCE
-    as a hipGraph on static batch buffers and replayed per step: with the towers' convolutions on the HIP kernels the eager
-    step is bound by the host's ~400 launches (5.5 ms), the replay by the GPU (4.6 ms; tools/train_graph.py).  Single process
-    only (the captured step holds no collective).  Construction leaves weights, optimiser state and step counter as they were:
-    the warm-up steps MIOpen and the allocator need run on a snapshot that is restored in place."""
-
-    def __init__(self, optimizer, network, bucket, example_batch, hip_convs=False, warmup=3):
-        if _dist_on():
-            raise RuntimeError("GraphedUpdate captures no collective: use update_weights in data-parallel runs")
-        dev = next(network.parameters()).device
-        self.optimizer, self.network, self.bucket = optimizer, network, bucket
-        self.static = tuple(torch.as_tensor(x, dtype=torch.float32).to(dev).clone() for x in example_batch)
-        had_state = {id(p): optimizer.state.get(p, {}).get("momentum_buffer") is not None for p in network.parameters()}
-        snap_w = [p.detach().clone() for p in network.parameters()]
-        snap_m = {id(p): optimizer.state[p]["momentum_buffer"].clone() for p in network.parameters() if had_state[id(p)]}
-        steps0, log = network.steps, globals()["LOG"]
-        globals()["LOG"] = None
-        try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    update_weights(optimizer, network, self.static, bucket, hip_convs=hip_convs)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = update_weights(optimizer, network, self.static, bucket, hip_convs=hip_convs)
-        finally:
-            globals()["LOG"] = log
-            network.steps = steps0
-        with torch.no_grad():   # back to the state before the warm-up, in place (the graph holds these addresses)
-            for p, w in zip(network.parameters(), snap_w):
-                p.copy_(w)
-                buf = optimizer.state.get(p, {}).get("momentum_buffer")
-                if buf is not None:
-                    if had_state[id(p)]:
-                        buf.copy_(snap_m[id(p)])
-                    else:
-                        buf.zero_()   # SGD's first step sets the buffer to the gradient: the same as momentum * 0 + gradient
-
-    def __call__(self, batch):
-        for d, t in zip(self.static, batch):
-            d.copy_(torch.as_tensor(t, dtype=torch.float32), non_blocking=True)
-        self.graph.replay()
-        p_loss, v_loss = self.out[0].clone(), self.out[1].clone()
-        if LOG is not None and self.network.steps % 10 == 0:   # main.py:268-269
-            LOG('step {}: p_loss {:.4f} v_loss {:.4f}'.format(self.network.steps, float(p_loss), float(v_loss)))
-        self.network.steps += 1
-        return p_loss, v_loss
-
-
 class SharedStorage:
     """network.py:169-178 without Ray: holds the latest published weights in-process"""
 

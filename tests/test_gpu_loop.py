@@ -55,31 +55,6 @@ def test_generations_with_hip_training_convolutions():
         config.num_unroll_steps = old
 
 
-def test_graphed_training_steps_in_the_loop():
-    """train_graph=True: the loop's training steps replayed as one hipGraph (train.GraphedUpdate), first built inside an
-    overlapped generation (on the second stream, while the games are being played); losses follow the eager loop's"""
-    from muzero_amd import config
-    from muzero_amd.loop import MuZeroLoop
-    old = config.num_unroll_steps
-    config.num_unroll_steps = 5
-    try:
-        out = {}
-        for graphed in (False, True):
-            loop = MuZeroLoop(64, num_simulations=6, window_size=64, batch_size=32, infer_dtype=torch.bfloat16, train_convs="hip", train_graph=graphed)
-            loop.generation(0)                                       # fills the window
-            losses = loop.generation(3, overlap=True) + loop.generation(2)
-            out[graphed] = np.array([(float(p), float(v)) for p, v in losses])
-            assert loop.network.steps == 5 and (loop._graphed is not None) == graphed
-            for a, b in zip(loop.infer.net.state_dict().values(), loop.network.state_dict().values()):
-                assert torch.equal(a, b.to(a.dtype))
-        assert np.isfinite(out[True]).all()
-        assert np.allclose(out[False][:3], out[True][:3], rtol=2e-3)   # same games, same draws, same kernels
-    finally:
-        config.num_unroll_steps = old
-    with pytest.raises(ValueError):
-        MuZeroLoop(8, num_simulations=2, window_size=16, batch_size=8, replay_mode="sharded", train_graph=True)
-
-
 def test_sharded_window_equals_replicated_on_one_rank():
     """replay_mode="sharded" (no trajectory gather, local batches weighted in the all-reduce) makes the same draws and the
     same updates as the replicated window; with one rank the two must agree exactly"""

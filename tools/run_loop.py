@@ -1,10 +1,10 @@
 """The whole MuZero loop on one GPU, end to end: G generations of (self-play -> replay window -> training -> publish),
 then the arena: trained network vs the initial one.
-python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax] [fp32|hip|hip_x3] [graph]
+python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax] [fp32|hip|hip_x3]
 Without lr/weight_decay the optimiser is the reference's (main.py:206: lr 1e-3, weight_decay 0.1 -- it hardly learns in
 a short run); give both to see the loop learn.  negamax = 1 sets config.negamax_value (non-default: the search maximises
 the mover's own value instead of the reference's child-mover value).  hip / hip_x3: the training step's tower convolutions on
-the hand-written kernels (bf16 / split precision); graph = 1: the step replayed as one hipGraph."""
+the hand-written kernels (bf16 / split precision)."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,9 +21,8 @@ if len(sys.argv) > 6 and int(sys.argv[6]):
     config.negamax_value = True
     print("config.negamax_value = True")
 convs = sys.argv[7] if len(sys.argv) > 7 else "fp32"
-graph = len(sys.argv) > 8 and bool(int(sys.argv[8]))
-print("training convolutions: %s, step as one hipGraph: %s" % (convs, graph))
-lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512, train_convs=convs, train_graph=graph)
+print("training convolutions: %s" % convs)
+lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512, train_convs=convs)
 init = copy.deepcopy(lp.network.state_dict())
 if len(sys.argv) > 5:
     lp.optimizer = torch.optim.SGD(lp.network.parameters(), lr=float(sys.argv[4]), momentum=config.momentum, weight_decay=float(sys.argv[5]))
@@ -32,6 +31,12 @@ t0 = time.perf_counter()
 for g in range(G):
     out = lp.generation(steps)
     torch.cuda.synchronize()
+    if any(not (float(a) == float(a) and float(b) == float(b)) for a, b in out):   # a non-finite loss: show the steps of this generation and stop
+        print("non-finite loss in generation %d; its steps (p_loss, v_loss):" % g)
+        print(" ".join("(%.4f, %.4f)" % (float(a), float(b)) for a, b in out), flush=True)
+        bad = [k for k, p in lp.network.named_parameters() if not torch.isfinite(p).all()]
+        print("non-finite parameters:", bad[:8], len(bad))
+        sys.exit(3)
     pl = sum(float(a) for a, _ in out) / max(1, len(out))
     vl = sum(float(b) for _, b in out) / max(1, len(out))
     print("generation %2d: %5d games in the window, %4d steps, mean p_loss %.4f v_loss %.4f, %.1f s elapsed" %
