@@ -479,6 +479,19 @@ int mz_conv3x3_pack_many(const float *const *w, void *const *packed_fwd, void *c
 int mz_conv3x3_wgrad_x3(const float *const *x, const float *const *g, const int64_t *n_boards, int32_t n_seg, float *dw, float *db,
                         int32_t accumulate, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* Split-precision SERVING: the three residual blocks of a tower (network.py:35-47 as used by Representation.conv2,
+ * network.py:59-61, and Dynamics' blocks, network.py:119-123) in ONE launch, LDS-resident:
+ *     for blk in 0..2:   x = relu(x + conv_{2 blk + 1}(relu(conv_{2 blk}(x) + b_{2 blk})) + b_{2 blk + 1})
+ * in the split precision described above (activations carried as hi / lo bf16 images in LDS, three products per convolution
+ * into one f32 accumulator, the skip path in f32 registers): within ~1e-5 of the fp32 modules, no HBM traffic between layers.
+ *   mz_restower_x3_pack : w = HOST array of the six convolutions' weights (128,128,3,3) f32 in order; packed = device buffer of
+ *                         MZ_RESTOWER_X3_PACKED_BYTES, 16-byte aligned.  Repack when the weights change.
+ *   mz_restower_x3_forward : bias (6,128) f32 contiguous, 16-byte aligned; x, y (n,128,8,8) f32 NCHW contiguous, x == y allowed;
+ *                         relu_in != 0 applies ReLU to x on load (the first convolution's activation, fused). */
+#define MZ_RESTOWER_X3_PACKED_BYTES ((18 * 36 + 4) * 4096 * 2)
+int mz_restower_x3_pack(const float *const *w, void *packed, void *stream);
+int mz_restower_x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(HERE, "lib", "libmuzero_amd.so")  # override: experiment builds
 
 MZ_F32, MZ_BF16, MZ_F16 = 0, 1, 2
+MZ_RESTOWER_X3_PACKED_BYTES = (18 * 36 + 4) * 4096 * 2   # include/muzero_amd.h
 ST_OK, ST_ILLEGAL, ST_DONE = 0, 1, 2
 VIS_I32, VIS_U16, VIS_U8 = 0, 1, 2
 
@@ -112,6 +113,8 @@ SIGNATURES = {
     "mz_conv3x3_pack_part": [_p, _p, _p, _i32, _p],
     "mz_conv3x3_pack_many": [_p, _p, _p, _i32, _i32, _p],
     "mz_conv3x3_wgrad_x3": [_p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p],
+    "mz_restower_x3_pack": [_p, _p, _p],
+    "mz_restower_x3_forward": [_p, _p, _p, _p, _i64, _i32, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

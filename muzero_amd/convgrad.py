@@ -116,3 +116,37 @@ def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, pa
         L.call("mz_conv3x3_fused", L.dptr(packed), None, L.dptr(x), 1, L.dptr(y), None, L.dptr(y), n, 0, st)
         L.call("mz_conv3x3_fused", L.dptr(packed_lo), None, L.dptr(x), 0, L.dptr(y), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
     return y
+
+
+RESTOWER_X3_ELEMS = L.MZ_RESTOWER_X3_PACKED_BYTES // 2
+
+
+def restower_x3_pack(weights, out=None):
+    """six (128,128,3,3) f32 convolution weights (a tower's three residual blocks, in order) -> the weight stream of
+    restower_x3 (mz_restower_x3_pack); out: an earlier result to refill in place"""
+    ws = [w.detach().contiguous() for w in weights]
+    if len(ws) != 6 or any((not w.is_cuda) or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) for w in ws):
+        raise L.MzError("restower_x3_pack: six cuda float32 (128,128,3,3) weights")
+    if out is None:
+        out = torch.empty(RESTOWER_X3_ELEMS, dtype=torch.bfloat16, device=ws[0].device)
+    elif out.dtype != torch.bfloat16 or out.numel() != RESTOWER_X3_ELEMS or not out.is_contiguous() or out.device != ws[0].device:
+        raise L.MzError("restower_x3_pack: out must come from an earlier call")
+    L.call("mz_restower_x3_pack", (C.c_void_p * 6)(*[w.data_ptr() for w in ws]), L.dptr(out), L.current_stream())
+    return out
+
+
+def restower_x3(x, packed, bias, relu_in=False, out=None):
+    """y = three residual blocks relu(h + conv(relu(conv(h)))) (network.py:35-47) applied to x (n,128,8,8) f32, in split
+    precision, as ONE LDS-resident launch (mz_restower_x3_forward).  bias: (6,128) f32; relu_in: x = relu(x) first; out may be x."""
+    _check(x, "restower_x3 input")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(out, "restower_x3 output")
+    if out.shape != x.shape or out.device != x.device or packed.device != x.device or bias.device != x.device:
+        raise L.MzError("restower_x3: mismatched tensors")
+    if packed.dtype != torch.bfloat16 or packed.numel() != RESTOWER_X3_ELEMS or not packed.is_contiguous():
+        raise L.MzError("restower_x3: packed must come from restower_x3_pack")
+    if bias.dtype != torch.float32 or tuple(bias.shape) != (6, 128) or not bias.is_contiguous():
+        raise L.MzError("restower_x3: bias must be a contiguous float32 (6,128) tensor")
+    L.call("mz_restower_x3_forward", L.dptr(packed), L.dptr(bias), L.dptr(x), L.dptr(out), x.shape[0], 1 if relu_in else 0, L.current_stream())
+    return out

@@ -209,7 +209,9 @@ typedef __attribute__((ext_vector_type(4))) float acc16_t;
 // 4-board tile: the training convolution on small batches, where twice the workgroups matter more than the K loop's density)
 template <int MODE, int NJ = 8>
 __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][NJ],
-                                          const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id) {
+                                          const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id, int xoff = OFF_X) {
+    // xoff: byte offset of the image the K loop READS (the split-precision tower keeps two: k_restower_x3); the MODE 0 / 1
+    // epilogues below work on the image at OFF_X
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     const int cobase = 64 * (w & 1), posbase = 16 * NJ * (w >> 1);
 
@@ -228,7 +230,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     auto set_tap = [&](int ky, int kx) {   // tap = 3 ky + kx
         const int dq = (ky - 1) * 8 + (kx - 1);
         const bool okx = (unsigned)(x + kx - 1) < 8u;
-        const int base = OFF_X + (posbase + p16 + dq) * 256;     // tile 0's shifted row; tile j: + 4096 j
+        const int base = xoff + (posbase + p16 + dq) * 256;      // tile 0's shifted row; tile j: + 4096 j
         ak = (kc ^ act_key((p16 + dq) & 15)) << 4;               // the key's bits (row parity, column) do not depend on the tile
         tbm = okx ? base : OFF_Z;
         tbt = okx && (y0 + ky - 1) >= 0 ? base : OFF_Z;          // tiles 0, 4 = board rows 0, 1
@@ -946,6 +948,124 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages) land before the wave ends
 }
 
+// ---- fp32-grade serving: the THREE RESIDUAL BLOCKS of a tower (network.py:35-47, six 3x3 128 -> 128 convolutions) in split
+// precision, LDS-resident.  k_conv3x3 in split precision is three launches per convolution, each a pass over fp32 tensors in
+// HBM (400 MB per launch at 4096 boards: the launches are HBM-bound).  Here a workgroup carries a 4-board tile through all six
+// layers: TWO [256 pos][128 ch] bf16 images (hi = bf16(v) at 0, lo = bf16(v - hi) at 64 KB) updated in place, three K loops
+// per layer into ONE set of fp32 accumulators -- W_hi x_hi, W_hi x_lo, W_lo x_hi: every product exact, fp32 sums, what is
+// dropped is W_lo x_lo ~ 2^-16 of a term -- and the block input x kept in fp32 REGISTERS for the skip path (64 per lane: the
+// 4-board tile's 64 accumulators leave room for it), so the residual sum sees no rounding at all.  HBM traffic: x once in, y
+// once out.  The weight stream is one array of 18 x 36 stages (per layer: hi, hi again, lo; + 4 stages of padding) that runs
+// through the ring without a break, like the serving kernel's.
+struct ResArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu_in; };
+constexpr int X3_LO = 65536;         // byte offset of the lo image
+constexpr int X3_SEGMENTS = 18;      // K loops per tile
+
+__device__ __forceinline__ void x3_store_images(char *lds, const acc16_t (&v)[4][4], int posbase, int p16, int kc, int cobase) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = posbase + 16 * j + p16;
+        char *row = lds + q * 256 + (kc & 1) * 8;
+        const int key = act_key(q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int chunk = (cobase >> 3) + 2 * i + (kc >> 1);   // channels cobase + 16 i + 4 kc + 0..3
+            char *p = row + ((chunk ^ key) << 4);
+            uint2 hi, lo;
+            hi.x = pack_bf16(v[i][j][0], v[i][j][1]);
+            hi.y = pack_bf16(v[i][j][2], v[i][j][3]);
+            // the rounding remainders: exact in f32, then rounded to bf16 themselves
+            lo.x = pack_bf16(v[i][j][0] - bf16_up(hi.x & 0xFFFFu), v[i][j][1] - __uint_as_float(hi.x & 0xFFFF0000u));
+            lo.y = pack_bf16(v[i][j][2] - bf16_up(hi.y & 0xFFFFu), v[i][j][3] - __uint_as_float(hi.y & 0xFFFF0000u));
+            *reinterpret_cast<uint2 *>(p) = hi;
+            *reinterpret_cast<uint2 *>(p + X3_LO) = lo;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int64_t board0 = (int64_t)blockIdx.x * 4;
+    mid_prologue(lds, a.w, tid);
+    const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
+    const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);   // wave = co half x board
+    const int64_t b = board0 + (w >> 1);
+    const bool live = b < a.n_boards;
+    const int64_t o = (b * 128 + cobase + 4 * kc) * 64 + p16;   // + 16 j cells, + (16 i + e) channels
+    acc16_t xk[4][4], acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = live ? a.x[o + 16 * j + (16 * i + e) * 64] : 0.0f;
+                xk[i][j][e] = a.relu_in ? fmaxf(v, 0.0f) : v;
+            }
+    x3_store_images(lds, xk, posbase, p16, kc, cobase);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
+    __syncthreads();
+    const Tower none{};
+    const uint4 *wp = a.w;
+#pragma unroll 1
+    for (int l = 0; l < 6; ++l) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + l * 128 + cobase + 16 * i + 4 * kc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (l & 1) ? xk[i][j] + bv : bv;   // a block's second convolution adds onto x
+        }
+#pragma unroll 1
+        for (int part = 0; part < 3; ++part) {   // W_hi x_hi, W_hi x_lo, W_lo x_hi
+            layer_mid<2, 4>(lds, wp, nullptr, acc, nullptr, tid, none, 0, part == 1 ? X3_LO : 0);
+            wp += N_STAGES * 512;
+        }
+        // in place: every wave must be through its reads of both images (the "tap 9" prefetches included)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.0f);
+                if (l & 1) xk[i][j] = acc[i][j];
+            }
+        if (l < 5) {
+            x3_store_images(lds, acc, posbase, p16, kc, cobase);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a.y[o + 16 * j + (16 * i + e) * 64] = xk[i][j][e];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages) land before the wave ends
+}
+
+// the six convolutions' weights (128,128,3,3) f32 -> k_restower_x3's stream: [18 x 36 + 4 stages][128 co][4 slots][8] bf16, segment
+// 3 l, 3 l + 1 = layer l's bf16 rounding, 3 l + 2 = its remainder; stage / row / slot layout as k_conv3x3_pack's forward image
+struct ResPackArgs { const float *w[6]; uint16_t *out; };
+__global__ void __launch_bounds__(256) k_restower_x3_pack(ResPackArgs a) {   // blockIdx.y = segment (18 = the padding)
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // (stage, row, slot, e)
+    const int seg = blockIdx.y;
+    if (seg == X3_SEGMENTS) {
+        if (idx < 4 * 4096) a.out[(size_t)X3_SEGMENTS * N_STAGES * 4096 + idx] = 0;
+        return;
+    }
+    const float *__restrict__ wsrc = a.w[seg / 3];
+    const int e = idx & 7, slot = (idx >> 3) & 3, row = (idx >> 5) & 127, stage = idx >> 12;
+    const int tap = stage >> 2, quarter = stage & 3, ky = tap / 3, kx = tap % 3;
+    const int ch = quarter * 32 + ((slot ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3) + e;
+    float wf = wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx];
+    if (seg % 3 == 2) wf -= bf16_up(bf16_rne(wf));
+    a.out[(size_t)seg * N_STAGES * 4096 + idx] = (uint16_t)bf16_rne(wf);
+}
+
 // conv weight (128 co, 128 ci, 3, 3) f32 -> the two stage images k_conv3x3 streams: [36 + 4 stages][128 rows][4 slots][8] bf16,
 //   forward : stage (ky*3+kx)*4 + ci/32, row co, element = W[co][ci][ky][kx]
 //   backward: stage (ky*3+kx)*4 + co/32, row ci, element = W[co][ci][2-ky][2-kx]   (the data gradient as a convolution of g)
@@ -1037,6 +1157,34 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
 
 extern "C" int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream) {
     return mz_conv3x3_fused(packed, bias, x, 0, nullptr, nullptr, y, n, relu, stream);
+}
+
+extern "C" int mz_restower_x3_pack(const float *const *w, void *packed, void *stream) {
+    MZ_REQUIRE(w && packed, "mz_restower_x3_pack: null pointer");
+    MZ_REQUIRE(((uintptr_t)packed & 15) == 0, "mz_restower_x3_pack: the output must be 16-byte aligned");
+    ResPackArgs a{};
+    for (int i = 0; i < 6; ++i) {
+        MZ_REQUIRE(w[i], "mz_restower_x3_pack: null pointer (convolution %d)", i);
+        a.w[i] = w[i];
+    }
+    a.out = (uint16_t *)packed;
+    hipLaunchKernelGGL(k_restower_x3_pack, dim3(N_STAGES * 4096 / 256, X3_SEGMENTS + 1), dim3(256), 0, (hipStream_t)stream, a);
+    MZ_LAUNCH_CHECK("k_restower_x3_pack");
+    return MZ_OK;
+}
+
+extern "C" int mz_restower_x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_restower_x3_forward: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(packed && bias && x && y, "mz_restower_x3_forward: null pointer");
+    MZ_REQUIRE((((uintptr_t)packed | (uintptr_t)bias) & 15) == 0, "mz_restower_x3_forward: packed weights and bias must be 16-byte aligned");
+    MZ_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 3) == 0, "mz_restower_x3_forward: x and y must be f32 tensors");
+    const int64_t n_tiles = (n + 3) / 4;
+    MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_restower_x3_forward: too many boards");
+    const ResArgs a{(const uint4 *)packed, bias, x, y, n, relu_in ? 1 : 0};
+    hipLaunchKernelGGL(k_restower_x3, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    MZ_LAUNCH_CHECK("k_restower_x3");
+    return MZ_OK;
 }
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,

@@ -222,24 +222,26 @@ class InferenceEngine:
 
     # ---- split-precision tower (fp32 serving) ------------------------------------------------------
     def _repack_x3(self):
-        """the mid convolutions' hi / lo weight images, (re)built IN PLACE (a captured hipGraph holds their addresses)"""
-        from .convgrad import PACKED_ELEMS, pack_conv
+        """the residual blocks' weight stream (hi, hi, lo per convolution) and their six biases, (re)built IN PLACE (a captured
+        hipGraph holds their addresses)"""
+        from .convgrad import restower_x3_pack
         for name, (_first, blocks, _last, _cin) in self._tower_parts().items():
-            for bi, blk in enumerate(blocks):
-                for ci in (0, 2):
-                    key = (name, bi, ci)
-                    if key not in self._packs3:
-                        self._packs3[key] = torch.empty((4, PACKED_ELEMS), dtype=torch.bfloat16, device=self.device)
-                    pack_conv(blk.block[ci].weight.contiguous(), out=self._packs3[key], split=True)
+            convs = [blk.block[ci] for blk in blocks for ci in (0, 2)]
+            if name not in self._packs3:
+                self._packs3[name] = (restower_x3_pack([c.weight for c in convs]), torch.empty((6, 128), dtype=torch.float32, device=self.device))
+            packed, bias = self._packs3[name]
+            restower_x3_pack([c.weight for c in convs], out=packed)
+            for i, c in enumerate(convs):
+                bias[i].copy_(c.bias.detach())
 
     def _tower_x3(self, name, x):
-        from .convgrad import conv3x3
-        first, blocks, last, _cin = self._tower_parts()[name]
-        y = F.relu(F.conv2d(x.contiguous(), first.weight, first.bias, 1, 1))
-        for bi, blk in enumerate(blocks):
-            p1, p2 = self._packs3[(name, bi, 0)], self._packs3[(name, bi, 2)]
-            t = conv3x3(y, p1[0], blk.block[0].bias, relu=True, packed_lo=p1[2])
-            y = conv3x3(t, p2[0], blk.block[2].bias, relu=True, skip=y, packed_lo=p2[2])   # relu(x + block(x)), network.py:46-47
+        """first and last convolution through PyTorch/MIOpen in fp32; between them the three residual blocks as ONE LDS-resident
+        launch in split precision (the first convolution's ReLU is applied on load, the result overwrites its output)"""
+        from .convgrad import restower_x3
+        first, _blocks, last, _cin = self._tower_parts()[name]
+        packed, bias = self._packs3[name]
+        y = F.conv2d(x.contiguous(), first.weight, first.bias, 1, 1)
+        restower_x3(y, packed, bias, relu_in=True, out=y)
         return F.relu(F.conv2d(y, last.weight, last.bias, 1, 1))
 
     # ---- HIP tower ---------------------------------------------------------------------------------

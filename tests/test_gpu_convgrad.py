@@ -173,6 +173,51 @@ def test_split_precision_kernels_are_close_to_fp32():
     assert ew <= 2e-5 and (db.double() - gb).abs().max().item() <= 1e-5 * gb.abs().max().item() + 1e-4
 
 
+@pytest.mark.parametrize("n", [1, 6, 64, 1030])
+def test_split_precision_residual_tower_matches_fp64(n):
+    """mz_restower_x3_forward: three residual blocks (network.py:35-47) in ONE LDS-resident launch, activations as hi / lo bf16
+    images, three products per convolution, the skip path in fp32 registers -- against the fp64 modules and against the chain
+    of single split-precision convolutions (three launches each)"""
+    from muzero_amd.convgrad import conv3x3, pack_conv, restower_x3, restower_x3_pack
+    g = torch.Generator(device="cuda").manual_seed(100 + n)
+    ws = [torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03 for _ in range(6)]
+    bias = torch.randn(6, 128, device="cuda", generator=g) * 0.2
+    x = torch.randn(n, 128, 8, 8, device="cuda", generator=g)
+    packed = restower_x3_pack(ws)
+    F = torch.nn.functional
+
+    def ref(h):
+        h = h.double()
+        for blk in range(3):
+            t = F.conv2d(h, ws[2 * blk].double(), bias[2 * blk].double(), padding=1).relu()
+            h = (h + F.conv2d(t, ws[2 * blk + 1].double(), bias[2 * blk + 1].double(), padding=1)).relu()
+        return h
+    want = ref(x)
+    got = restower_x3(x, packed, bias)
+    err = (got.double() - want).norm().item() / want.norm().item()
+    print("residual tower, %d boards: relative L2 error %.3g, max %.3g of max %.3g" % (n, err, (got.double() - want).abs().max().item(), want.abs().max().item()))
+    assert err <= 2e-5
+    assert (got.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    # the chain of single convolutions computes the same products; it sums them in another order and rounds the skip path
+    # through fp32 tensors in HBM, not through registers
+    h = x
+    for blk in range(3):
+        p1, p2 = pack_conv(ws[2 * blk], split=True), pack_conv(ws[2 * blk + 1], split=True)
+        t = conv3x3(h, p1[0], bias[2 * blk], relu=True, packed_lo=p1[2])
+        h = conv3x3(t, p2[0], bias[2 * blk + 1], relu=True, skip=h, packed_lo=p2[2])
+    assert (got - h).norm().item() <= 2e-5 * h.norm().item()
+    # ReLU on load, in place, and the same bits again
+    want2 = ref(x.relu())
+    y = x.clone()
+    assert restower_x3(y, packed, bias, relu_in=True, out=y) is y
+    assert (y.double() - want2).norm().item() <= 2e-5 * want2.norm().item()
+    assert torch.equal(restower_x3(x.relu(), packed, bias), y)
+    # repacking in place serves the new weights
+    ws2 = [w.flip(0) for w in ws]
+    restower_x3_pack(ws2, out=packed)
+    assert torch.equal(restower_x3(x, packed, bias), restower_x3(x, restower_x3_pack(ws2), bias))
+
+
 def test_training_gradients_in_split_precision_match_the_fp32_step():
     """the K = 5 unrolled loss with the towers in split precision against the fp32 PyTorch/MIOpen step (itself Winograd
     arithmetic, not exact sums): measured on MI355X worst tensor 1.0e-3, median 1.7e-4 -- 50-90 x closer than the one-product
