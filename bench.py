@@ -677,10 +677,16 @@ def main():
                     engx.search(image32, noise)
                 torch.cuda.synchronize()
                 dtx = (time.perf_counter() - t1) / args.fp32_steps
+                msx = event_time_ms(lambda: netx.recurrent(engx.mcts.net_in), 10)
+                tfx = n * NET_MFLOP * 1e6 / (msx * 1e-3) / 1e12
                 out["fp32_split_precision_inference"] = dict(
                     value=n * S / dtx, unit="simulations/s", ms_per_step=dtx * 1e3, steps=args.fp32_steps,
-                    inference="fp32 serving, the towers' 128 -> 128 convolutions on k_conv3x3 in split precision (three bf16 MFMA products per fp32 "
-                              "product, fused ReLU / residual), first / last convolutions and heads through PyTorch fp32",
+                    inference="fp32 serving: each tower (first convolution, three residual blocks, last convolution) as ONE LDS-resident launch in "
+                              "split precision (k_restower_x3: hi / lo bf16 activation images, three bf16 MFMA products per fp32 product, fp32 sums, "
+                              "skip path in fp32 registers), heads through PyTorch fp32",
+                    roofline={"bound": "mfma", "achieved": 3 * tfx, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3 * tfx / BF16_PEAK_TFLOPS,
+                              "us_per_launch_sequence": msx * 1e3, "fp32_grade_tflops": tfx,
+                              "note": "bf16 MFMA work = 3 x the network's FLOPs, over the whole recurrent inference call (tower launch + heads)"},
                     agreement_with_fp32_search=visit_agreement(fp32_visits, x3_visits))
                 del engx, netx
             except Exception as e:   # noqa: BLE001  (optional leg)

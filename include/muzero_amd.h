@@ -488,9 +488,21 @@ int mz_conv3x3_wgrad_x3(const float *const *x, const float *const *g, const int6
  *                         MZ_RESTOWER_X3_PACKED_BYTES, 16-byte aligned.  Repack when the weights change.
  *   mz_restower_x3_forward : bias (6,128) f32 contiguous, 16-byte aligned; x, y (n,128,8,8) f32 NCHW contiguous, x == y allowed;
  *                         relu_in != 0 applies ReLU to x on load (the first convolution's activation, fused). */
-#define MZ_RESTOWER_X3_PACKED_BYTES ((18 * 36 + 4) * 4096 * 2)
+#define MZ_RESTOWER_X3_PACKED_BYTES ((12 * 36 + 4) * 4096 * 2)
 int mz_restower_x3_pack(const float *const *w, void *packed, void *stream);
 int mz_restower_x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream);
+/* The WHOLE tower in that form (Representation network.py:49-77, Dynamics' convolutions network.py:113-135): first convolution
+ * (cin -> 128, + ReLU), the three blocks, last convolution (128 -> 8, + ReLU), one launch, planes in, hidden state out:
+ *   mz_tower_x3_pack_ends : w_first (128, cin, 3, 3) f32, w_last (8, 128, 3, 3) f32 -> ends, MZ_TOWER_X3_ENDS_BYTES, 16-byte aligned
+ *   mz_tower_x3_forward   : packed / bias as above; b_first (128) / b_last (8) f32 or NULL (Dynamics has none); x (n, cin, 8, 8) f32,
+ *                           hidden (n, 8, 8, 8) f32, both NCHW contiguous, x != hidden. */
+#define MZ_TOWER_X3_ENDS_BYTES ((2 * 5 * 128 * 32 + 2 * 4 * 80 * 32) * 2)
+int mz_tower_x3_pack_ends(const float *w_first, int32_t cin, const float *w_last, void *ends, void *stream);
+int mz_tower_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                        const float *x, float *hidden, int64_t n, void *stream);
+/* diagnostics: the same launch (relu_in = 0) writing shader-cycle stamps at the phase boundaries of every 4-board tile into
+ * stamps, (ceil(n / 4), 32) int64 on the device (tools/restower_stamps.py reads them) */
+int mz_restower_x3_stamps(const void *packed, const float *bias, const float *x, float *y, int64_t n, void *stamps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(HERE, "lib", "libmuzero_amd.so")  # override: experiment builds
 
 MZ_F32, MZ_BF16, MZ_F16 = 0, 1, 2
-MZ_RESTOWER_X3_PACKED_BYTES = (18 * 36 + 4) * 4096 * 2   # include/muzero_amd.h
+MZ_RESTOWER_X3_PACKED_BYTES = (12 * 36 + 4) * 4096 * 2
+MZ_TOWER_X3_ENDS_BYTES = (2 * 5 * 128 * 32 + 2 * 4 * 80 * 32) * 2   # include/muzero_amd.h
 ST_OK, ST_ILLEGAL, ST_DONE = 0, 1, 2
 VIS_I32, VIS_U16, VIS_U8 = 0, 1, 2
 
@@ -115,6 +116,9 @@ SIGNATURES = {
     "mz_conv3x3_wgrad_x3": [_p, _p, _p, _i32, _p, _p, _i32, _p, _i64, _p],
     "mz_restower_x3_pack": [_p, _p, _p],
     "mz_restower_x3_forward": [_p, _p, _p, _p, _i64, _i32, _p],
+    "mz_restower_x3_stamps": [_p, _p, _p, _p, _i64, _p, _p],
+    "mz_tower_x3_pack_ends": [_p, _i32, _p, _p, _p],
+    "mz_tower_x3_forward": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

@@ -150,3 +150,45 @@ def restower_x3(x, packed, bias, relu_in=False, out=None):
         raise L.MzError("restower_x3: bias must be a contiguous float32 (6,128) tensor")
     L.call("mz_restower_x3_forward", L.dptr(packed), L.dptr(bias), L.dptr(x), L.dptr(out), x.shape[0], 1 if relu_in else 0, L.current_stream())
     return out
+
+
+TOWER_X3_ENDS_ELEMS = L.MZ_TOWER_X3_ENDS_BYTES // 2
+
+
+def tower_x3_pack_ends(w_first, w_last, out=None):
+    """first (128,cin,3,3) and last (8,128,3,3) convolution weights of a tower -> the fragment arrays of tower_x3
+    (mz_tower_x3_pack_ends); out: an earlier result to refill in place"""
+    wf, wl = w_first.detach().contiguous(), w_last.detach().contiguous()
+    cin = wf.shape[1] if wf.dim() == 4 else 0
+    if (not wf.is_cuda or wf.dtype != torch.float32 or wf.dim() != 4 or tuple(wf.shape) != (128, cin, 3, 3) or not 1 <= cin <= 16
+            or wl.device != wf.device or wl.dtype != torch.float32 or tuple(wl.shape) != (8, 128, 3, 3)):
+        raise L.MzError("tower_x3_pack_ends: cuda float32 weights of shape (128,cin<=16,3,3) and (8,128,3,3)")
+    if out is None:
+        out = torch.empty(TOWER_X3_ENDS_ELEMS, dtype=torch.bfloat16, device=wf.device)
+    elif out.dtype != torch.bfloat16 or out.numel() != TOWER_X3_ENDS_ELEMS or not out.is_contiguous() or out.device != wf.device:
+        raise L.MzError("tower_x3_pack_ends: out must come from an earlier call")
+    L.call("mz_tower_x3_pack_ends", L.dptr(wf), cin, L.dptr(wl), L.dptr(out), L.current_stream())
+    return out
+
+
+def tower_x3(x, packed, ends, bias, b_first=None, b_last=None, out=None):
+    """hidden (n,8,8,8) = relu(conv_last(blocks(relu(conv_first(x))))) for x (n,cin,8,8) f32: a whole tower (network.py:49-77 /
+    :113-135) in split precision as ONE LDS-resident launch (mz_tower_x3_forward)"""
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4 or tuple(x.shape[2:]) != (8, 8) or not 1 <= x.shape[1] <= 16:
+        raise L.MzError("tower_x3: need a contiguous cuda float32 (n, cin <= 16, 8, 8) input, got %s %s on %s" % (tuple(x.shape), x.dtype, x.device))
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, 8, 8, 8), dtype=torch.float32, device=x.device)
+    if out.dtype != torch.float32 or tuple(out.shape) != (n, 8, 8, 8) or not out.is_contiguous() or out.device != x.device:
+        raise L.MzError("tower_x3: out must be a contiguous float32 (n,8,8,8) tensor on the input's device")
+    if packed.dtype != torch.bfloat16 or packed.numel() != RESTOWER_X3_ELEMS or ends.dtype != torch.bfloat16 or ends.numel() != TOWER_X3_ENDS_ELEMS:
+        raise L.MzError("tower_x3: packed / ends must come from restower_x3_pack / tower_x3_pack_ends")
+    if bias.dtype != torch.float32 or tuple(bias.shape) != (6, 128) or not bias.is_contiguous():
+        raise L.MzError("tower_x3: bias must be a contiguous float32 (6,128) tensor")
+    for t, k in ((b_first, 128), (b_last, 8)):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (k,) or not t.is_contiguous() or t.device != x.device):
+            raise L.MzError("tower_x3: b_first / b_last must be contiguous float32 (128,) / (8,) tensors")
+    if packed.device != x.device or ends.device != x.device or bias.device != x.device:
+        raise L.MzError("tower_x3: tensors on different devices")
+    L.call("mz_tower_x3_forward", L.dptr(packed), L.dptr(ends), L.dptr(bias), L.dptr(b_first), L.dptr(b_last), x.shape[1], L.dptr(x), L.dptr(out), n, L.current_stream())
+    return out

@@ -207,13 +207,18 @@ typedef __attribute__((ext_vector_type(4))) float acc16_t;
 
 // NJ = position tiles per wave: 8 (two boards per wave, the 8-board tile of the serving kernel) or 4 (one board per wave, a
 // 4-board tile: the training convolution on small batches, where twice the workgroups matter more than the K loop's density)
-template <int MODE, int NJ = 8>
-__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][NJ],
+// DUAL (the split-precision tower, k_restower_x3): the NJ position tiles are NJ / 2 real tiles read from TWO images (hi at 0, lo
+// at X3_LO) that accumulate into the same NJ / 2 accumulators: one weight stage feeds W x_hi and W x_lo, 32 MFMAs per 12 fragment
+// reads like the 8-board tile, on a 4-board tile.
+constexpr int X3_LO = 65536;         // byte offset of the lo image
+template <int MODE, int NJ = 8, bool DUAL = false>
+__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][DUAL ? NJ / 2 : NJ],
                                           const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id, int xoff = OFF_X) {
     // xoff: byte offset of the image the K loop READS (the split-precision tower keeps two: k_restower_x3); the MODE 0 / 1
     // epilogues below work on the image at OFF_X
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
-    const int cobase = 64 * (w & 1), posbase = 16 * NJ * (w >> 1);
+    constexpr int NA = DUAL ? NJ / 2 : NJ;   // accumulator tiles per wave
+    const int cobase = 64 * (w & 1), posbase = 16 * NA * (w >> 1);
 
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
     int waddr[4];
@@ -242,7 +247,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
         at = tbt + off;
         ab = tbb + off;
     };
-    auto bfrag = [&](int j) { return lds_frag(lds + ((j & 3) == 0 ? at : ((j & 3) == 3 ? ab : am)) + j * 4096); };
+    auto bfrag = [&](int j) { return lds_frag(lds + ((j & 3) == 0 ? at : ((j & 3) == 3 ? ab : am)) + (j & (NA - 1)) * 4096 + (j / NA) * X3_LO); };
 
     bf16x8 a[2][4], b[4];
     set_tap(0, 0);
@@ -269,13 +274,13 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[0], b[j & 3], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[1], b[j & 3], acc[1][j], 0, 0, 0);
+                acc[0][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[0], b[j & 3], acc[0][j & (NA - 1)], 0, 0, 0);
+                acc[1][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[1], b[j & 3], acc[1][j & (NA - 1)], 0, 0, 0);
                 MZ_FENCE();
                 b[(j + 3) & 3] = bfrag((j + 3) & (NJ - 1));   // j <= 4: this stage's tile j + 3; j >= 5: the next stage's tile j - 5 (its addresses are set behind j = 4)
                 MZ_FENCE();
-                acc[2][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[2], b[j & 3], acc[2][j], 0, 0, 0);
-                acc[3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[3], b[j & 3], acc[3][j], 0, 0, 0);
+                acc[2][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[2], b[j & 3], acc[2][j & (NA - 1)], 0, 0, 0);
+                acc[3][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[3], b[j & 3], acc[3][j & (NA - 1)], 0, 0, 0);
                 MZ_FENCE();
                 if (j < 4) {
                     na[j] = lds_frag(lds + nbuf + waddr[j]);
@@ -952,14 +957,23 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
 // precision, LDS-resident.  k_conv3x3 in split precision is three launches per convolution, each a pass over fp32 tensors in
 // HBM (400 MB per launch at 4096 boards: the launches are HBM-bound).  Here a workgroup carries a 4-board tile through all six
 // layers: TWO [256 pos][128 ch] bf16 images (hi = bf16(v) at 0, lo = bf16(v - hi) at 64 KB) updated in place, three K loops
-// per layer into ONE set of fp32 accumulators -- W_hi x_hi, W_hi x_lo, W_lo x_hi: every product exact, fp32 sums, what is
+// per layer into ONE set of fp32 accumulators -- W_hi (x_hi | x_lo) in one K loop, then W_lo x_hi: every product exact, fp32 sums, what is
 // dropped is W_lo x_lo ~ 2^-16 of a term -- and the block input x kept in fp32 REGISTERS for the skip path (64 per lane: the
 // 4-board tile's 64 accumulators leave room for it), so the residual sum sees no rounding at all.  HBM traffic: x once in, y
-// once out.  The weight stream is one array of 18 x 36 stages (per layer: hi, hi again, lo; + 4 stages of padding) that runs
+// once out.  The weight stream is one array of 12 x 36 stages (per layer: hi, lo; + 4 stages of padding) that runs
 // through the ring without a break, like the serving kernel's.
-struct ResArgs { const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu_in; };
-constexpr int X3_LO = 65536;         // byte offset of the lo image
-constexpr int X3_SEGMENTS = 18;      // K loops per tile
+// FULL (mz_tower_x3_forward): the whole tower -- the first convolution (cin -> 128, network.py:53 / :68) in front and the last one
+// (128 -> 8, network.py:55 / :69) behind the blocks, in the same split precision: x = the (n, cin, 8, 8) input planes, y = the
+// (n, 8, 8, 8) hidden state; no 128-channel tensor touches HBM at all.
+struct ResArgs {
+    const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu_in; long long *stamps;
+    const uint16_t *ends; const float *b_first; const float *b_last; int cin;   // FULL only
+};
+// ends = the two small convolutions' MFMA fragments, read straight from global memory (L2-resident, the same for every tile):
+//   first: [2 parts][5 k-steps][128 co][32] bf16, k = 16 t2 + c -> tap 2 ks + t2, input plane c (zero beyond tap 8 / plane cin - 1)
+//   last : [2 parts][4 quarters][80 rows][32 ci] bf16, row = tap * 8 + plane (72 real)          part 0 = bf16 rounding, 1 = remainder
+constexpr int X3_FIRST_ELEMS = 5 * 128 * 32, X3_LAST_ELEMS = 4 * LAST_ROWS * 32, X3_ENDS_ELEMS = 2 * X3_FIRST_ELEMS + 2 * X3_LAST_ELEMS;
+constexpr int X3_SEGMENTS = 12;      // weight segments per tile: per layer the bf16 rounding (hi), then its remainder (lo)
 
 __device__ __forceinline__ void x3_store_images(char *lds, const acc16_t (&v)[4][4], int posbase, int p16, int kc, int cobase) {
 #pragma unroll
@@ -983,10 +997,15 @@ __device__ __forceinline__ void x3_store_images(char *lds, const acc16_t (&v)[4]
     }
 }
 
+template <bool FULL>
 __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
     const int64_t board0 = (int64_t)blockIdx.x * 4;
+    Tower none{};   // diagnostics only: [tiles][32] cycle stamps at the phase boundaries (tools/restower_stamps.py)
+    none.stamps = a.stamps ? a.stamps + (int64_t)blockIdx.x * 32 : nullptr;
+    if (none.stamps && tid == 0) none.stamps[30] = (long long)__builtin_amdgcn_s_memrealtime();
+    MZ_STAMP(none, 0);
     mid_prologue(lds, a.w, tid);
     const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
     const int cobase = 64 * (w & 1), posbase = 64 * (w >> 1);   // wave = co half x board
@@ -994,19 +1013,82 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
     const bool live = b < a.n_boards;
     const int64_t o = (b * 128 + cobase + 4 * kc) * 64 + p16;   // + 16 j cells, + (16 i + e) channels
     acc16_t xk[4][4], acc[4][4];
+    if (FULL) {
+        // first convolution.  Input planes -> hi / lo [256 pos][16 planes] bf16 at 0 / 8 KB (inside the images' region, not yet
+        // written); one k-step of the 16x16x32 MFMA = two taps x 16 planes, so its output lands in the K loops' accumulator layout
+        {
+            const int q = tid & 255, half = tid >> 8;
+            const int64_t bb = board0 + (q >> 6);
+            float v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 8; ++k) v[k] = (bb < a.n_boards && half * 8 + k < a.cin) ? a.x[(bb * a.cin + half * 8 + k) * 64 + (q & 63)] : 0.0f;
+            uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = live ? a.x[o + 16 * j + (16 * i + e) * 64] : 0.0f;
-                xk[i][j][e] = a.relu_in ? fmaxf(v, 0.0f) : v;
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = pack_bf16(v[2 * k], v[2 * k + 1]);
+                lo[k] = pack_bf16(v[2 * k] - bf16_up(hi[k] & 0xFFFFu), v[2 * k + 1] - __uint_as_float(hi[k] & 0xFFFF0000u));
             }
+            *reinterpret_cast<uint4 *>(lds + q * 32 + half * 16) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4 *>(lds + 8192 + q * 32 + half * 16) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 bv = a.b_first ? *reinterpret_cast<const f32x4 *>(a.b_first + cobase + 16 * i + 4 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = bv;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            const int tap = 2 * ks + (kc >> 1);   // this lane's half of the k-step
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint16_t *src = a.ends + (ks * 128 + cobase + 16 * i + (lane & 15)) * 32 + 8 * kc;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(src);
+                al[i] = *reinterpret_cast<const bf16x8 *>(src + X3_FIRST_ELEMS);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cell = 16 * j + p16;
+                const bool ok = tap < 9 && (unsigned)((cell & 7) + kx - 1) < 8u && (unsigned)((cell >> 3) + ky - 1) < 8u;
+                const int addr = ok ? (posbase + cell + (ky - 1) * 8 + (kx - 1)) * 32 + (kc & 1) * 16 : OFF_Z;
+                bh[j] = lds_frag(lds + addr);
+                bl[j] = lds_frag(lds + addr + 8192);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        // every wave has read the staged planes: the images may be written over them
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xk[i][j][e] = fmaxf(acc[i][j][e], 0.0f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = live ? a.x[o + 16 * j + (16 * i + e) * 64] : 0.0f;
+                    xk[i][j][e] = a.relu_in ? fmaxf(v, 0.0f) : v;
+                }
+    }
     x3_store_images(lds, xk, posbase, p16, kc, cobase);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
     __syncthreads();
-    const Tower none{};
+    MZ_STAMP(none, 1);
     const uint4 *wp = a.w;
 #pragma unroll 1
     for (int l = 0; l < 6; ++l) {
@@ -1016,11 +1098,9 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (l & 1) ? xk[i][j] + bv : bv;   // a block's second convolution adds onto x
         }
-#pragma unroll 1
-        for (int part = 0; part < 3; ++part) {   // W_hi x_hi, W_hi x_lo, W_lo x_hi
-            layer_mid<2, 4>(lds, wp, nullptr, acc, nullptr, tid, none, 0, part == 1 ? X3_LO : 0);
-            wp += N_STAGES * 512;
-        }
+        layer_mid<2, 8, true>(lds, wp, nullptr, acc, nullptr, tid, none, 2 + 3 * l);   // W_hi x_hi + W_hi x_lo
+        layer_mid<2, 4>(lds, wp + N_STAGES * 512, nullptr, acc, nullptr, tid, none, 3 + 3 * l);   // W_lo x_hi
+        wp += 2 * N_STAGES * 512;
         // in place: every wave must be through its reads of both images (the "tap 9" prefetches included)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
@@ -1031,12 +1111,82 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.0f);
                 if (l & 1) xk[i][j] = acc[i][j];
             }
-        if (l < 5) {
+        if (FULL || l < 5) {
             x3_store_images(lds, acc, posbase, p16, kc, cobase);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        MZ_STAMP(none, 4 + 3 * l);
     }
-    if (live) {
+    if (FULL) {
+        // last convolution, as layer_last: the nine taps in the M dimension (P[tap * 8 + plane][pos], K = 128), then every lane sums
+        // the nine shifted taps of one cell.  Even waves take their board, odd waves only keep the barriers.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages): the ring is dead
+        const bool mine = (w & 1) == 0;
+        bf16x8 fh[4][4], fl[4][4];
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = posbase + 16 * j + p16;
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const char *p = lds + q * 256 + (((4 * kq + kc) ^ act_key(q)) << 4);
+                    fh[j][kq] = lds_frag(p);
+                    fl[j][kq] = lds_frag(p + X3_LO);
+                }
+            }
+        }
+        // every wave holds its fragments in registers: the images may be overwritten by the partial sums
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float *P = reinterpret_cast<float *>(lds + (w >> 1) * P_WAVE_BYTES);
+        if (mine) {
+            const uint16_t *wl = a.ends + 2 * X3_FIRST_ELEMS;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                bf16x8 ah[4], al[4];
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const uint16_t *src = wl + (kq * LAST_ROWS + 16 * m + (lane & 15)) * 32 + 8 * kc;
+                    ah[kq] = *reinterpret_cast<const bf16x8 *>(src);
+                    al[kq] = *reinterpret_cast<const bf16x8 *>(src + X3_LAST_ELEMS);
+                }
+                const int tap = 2 * m + (kc >> 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc16_t pm = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kq], fh[j][kq], pm, 0, 0, 0);
+                        pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kq], fl[j][kq], pm, 0, 0, 0);
+                        pm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kq], fh[j][kq], pm, 0, 0, 0);
+                    }
+                    if (tap < 9) *reinterpret_cast<f32x4 *>(P + ((tap * 2 + (kc & 1)) * 64 + 16 * j + p16) * 4) = pm;
+                }
+            }
+            // gather: lane -> cell of the wave's board, both plane halves (the LDS serves a wave in order: no barrier needed)
+            const int q = lane, x = q & 7, y = q >> 3;
+            f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (a.b_last) {
+                s0 = *reinterpret_cast<const f32x4 *>(a.b_last);
+                s1 = *reinterpret_cast<const f32x4 *>(a.b_last + 4);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const bool ok = (unsigned)(x + kx - 1) < 8u && (unsigned)(y + ky - 1) < 8u;
+                const int q2 = (q + (ky - 1) * 8 + (kx - 1)) & 63;
+                const f32x4 p0 = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + 0) * 64 + q2) * 4);
+                const f32x4 p1 = *reinterpret_cast<const f32x4 *>(P + ((tap * 2 + 1) * 64 + q2) * 4);
+                if (ok) {
+                    s0 += p0;
+                    s1 += p1;
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a.y[b * 512 + k * 64 + lane] = fmaxf(k < 4 ? s0[k & 3] : s1[k & 3], 0.0f);
+            }
+        }
+    } else if (live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1045,25 +1195,49 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
                 for (int e = 0; e < 4; ++e) a.y[o + 16 * j + (16 * i + e) * 64] = xk[i][j][e];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages) land before the wave ends
+    MZ_STAMP(none, 20);
+    if (none.stamps && tid == 0) none.stamps[31] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
-// the six convolutions' weights (128,128,3,3) f32 -> k_restower_x3's stream: [18 x 36 + 4 stages][128 co][4 slots][8] bf16, segment
-// 3 l, 3 l + 1 = layer l's bf16 rounding, 3 l + 2 = its remainder; stage / row / slot layout as k_conv3x3_pack's forward image
+// the six convolutions' weights (128,128,3,3) f32 -> k_restower_x3's stream: [12 x 36 + 4 stages][128 co][4 slots][8] bf16, segment
+// 2 l = layer l's bf16 rounding, 2 l + 1 = its remainder; stage / row / slot layout as k_conv3x3_pack's forward image
 struct ResPackArgs { const float *w[6]; uint16_t *out; };
-__global__ void __launch_bounds__(256) k_restower_x3_pack(ResPackArgs a) {   // blockIdx.y = segment (18 = the padding)
+__global__ void __launch_bounds__(256) k_restower_x3_pack(ResPackArgs a) {   // blockIdx.y = segment (12 = the padding)
     const int idx = blockIdx.x * 256 + threadIdx.x;   // (stage, row, slot, e)
     const int seg = blockIdx.y;
     if (seg == X3_SEGMENTS) {
         if (idx < 4 * 4096) a.out[(size_t)X3_SEGMENTS * N_STAGES * 4096 + idx] = 0;
         return;
     }
-    const float *__restrict__ wsrc = a.w[seg / 3];
+    const float *__restrict__ wsrc = a.w[seg / 2];
     const int e = idx & 7, slot = (idx >> 3) & 3, row = (idx >> 5) & 127, stage = idx >> 12;
     const int tap = stage >> 2, quarter = stage & 3, ky = tap / 3, kx = tap % 3;
     const int ch = quarter * 32 + ((slot ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3) + e;
     float wf = wsrc[((row * 128 + ch) * 3 + ky) * 3 + kx];
-    if (seg % 3 == 2) wf -= bf16_up(bf16_rne(wf));
+    if (seg & 1) wf -= bf16_up(bf16_rne(wf));
     a.out[(size_t)seg * N_STAGES * 4096 + idx] = (uint16_t)bf16_rne(wf);
+}
+
+// the first (128, cin, 3, 3) and last (8, 128, 3, 3) convolutions' weights -> ResArgs::ends
+__global__ void __launch_bounds__(256) k_tower_x3_pack_ends(const float *__restrict__ w_first, int cin, const float *__restrict__ w_last, uint16_t *__restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= X3_ENDS_ELEMS) return;
+    float v = 0.0f;
+    int part;
+    if (idx < 2 * X3_FIRST_ELEMS) {
+        part = idx / X3_FIRST_ELEMS;
+        const int r = idx % X3_FIRST_ELEMS, k32 = r & 31, co = (r >> 5) & 127, ks = r >> 12;
+        const int tap = 2 * ks + (k32 >> 4), c = k32 & 15;
+        if (tap < 9 && c < cin) v = w_first[((co * cin + c) * 3 + tap / 3) * 3 + tap % 3];
+    } else {
+        const int r0 = idx - 2 * X3_FIRST_ELEMS;
+        part = r0 / X3_LAST_ELEMS;
+        const int r = r0 % X3_LAST_ELEMS, k32 = r & 31, row = (r >> 5) % LAST_ROWS, kq = (r >> 5) / LAST_ROWS;
+        const int tap = row >> 3, plane = row & 7;
+        if (row < 72) v = w_last[((plane * 128 + 32 * kq + k32) * 3 + tap / 3) * 3 + tap % 3];
+    }
+    if (part) v -= bf16_up(bf16_rne(v));
+    out[idx] = (uint16_t)bf16_rne(v);
 }
 
 // conv weight (128 co, 128 ci, 3, 3) f32 -> the two stage images k_conv3x3 streams: [36 + 4 stages][128 rows][4 slots][8] bf16,
@@ -1173,7 +1347,33 @@ extern "C" int mz_restower_x3_pack(const float *const *w, void *packed, void *st
     return MZ_OK;
 }
 
-extern "C" int mz_restower_x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream) {
+extern "C" int mz_tower_x3_pack_ends(const float *w_first, int32_t cin, const float *w_last, void *ends, void *stream) {
+    MZ_REQUIRE(w_first && w_last && ends, "mz_tower_x3_pack_ends: null pointer");
+    MZ_REQUIRE(cin >= 1 && cin <= 16, "mz_tower_x3_pack_ends: cin %d outside [1, 16]", cin);
+    MZ_REQUIRE(((uintptr_t)ends & 15) == 0, "mz_tower_x3_pack_ends: the output must be 16-byte aligned");
+    hipLaunchKernelGGL(k_tower_x3_pack_ends, dim3((X3_ENDS_ELEMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_first, (int)cin, w_last, (uint16_t *)ends);
+    MZ_LAUNCH_CHECK("k_tower_x3_pack_ends");
+    return MZ_OK;
+}
+
+extern "C" int mz_tower_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                                  const float *x, float *hidden, int64_t n, void *stream) {
+    MZ_REQUIRE(n >= 0, "mz_tower_x3_forward: n < 0");
+    if (n == 0) return MZ_OK;
+    MZ_REQUIRE(packed && ends && bias && x && hidden, "mz_tower_x3_forward: null pointer");
+    MZ_REQUIRE(cin >= 1 && cin <= 16, "mz_tower_x3_forward: cin %d outside [1, 16]", cin);
+    MZ_REQUIRE((((uintptr_t)packed | (uintptr_t)ends | (uintptr_t)bias | (uintptr_t)b_first | (uintptr_t)b_last) & 15) == 0,
+               "mz_tower_x3_forward: weights and biases must be 16-byte aligned");
+    MZ_REQUIRE((const void *)x != (const void *)hidden, "mz_tower_x3_forward: in-place call");
+    const int64_t n_tiles = (n + 3) / 4;
+    MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_tower_x3_forward: too many boards");
+    const ResArgs a{(const uint4 *)packed, bias, x, hidden, n, 0, nullptr, (const uint16_t *)ends, b_first, b_last, (int)cin};
+    hipLaunchKernelGGL(k_restower_x3<true>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    MZ_LAUNCH_CHECK("k_restower_x3<full>");
+    return MZ_OK;
+}
+
+static int restower_x3_launch(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream, long long *stamps) {
     MZ_REQUIRE(n >= 0, "mz_restower_x3_forward: n < 0");
     if (n == 0) return MZ_OK;
     MZ_REQUIRE(packed && bias && x && y, "mz_restower_x3_forward: null pointer");
@@ -1181,10 +1381,19 @@ extern "C" int mz_restower_x3_forward(const void *packed, const float *bias, con
     MZ_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 3) == 0, "mz_restower_x3_forward: x and y must be f32 tensors");
     const int64_t n_tiles = (n + 3) / 4;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_restower_x3_forward: too many boards");
-    const ResArgs a{(const uint4 *)packed, bias, x, y, n, relu_in ? 1 : 0};
-    hipLaunchKernelGGL(k_restower_x3, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
+    const ResArgs a{(const uint4 *)packed, bias, x, y, n, relu_in ? 1 : 0, stamps, nullptr, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(k_restower_x3<false>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_restower_x3");
     return MZ_OK;
+}
+
+extern "C" int mz_restower_x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream) {
+    return restower_x3_launch(packed, bias, x, y, n, relu_in, stream, nullptr);
+}
+// diagnostics (tools/restower_stamps.py): the same launch with per-tile cycle stamps, (ceil(n / 4), 32) int64
+extern "C" int mz_restower_x3_stamps(const void *packed, const float *bias, const float *x, float *y, int64_t n, void *stamps, void *stream) {
+    MZ_REQUIRE(stamps, "mz_restower_x3_stamps: null pointer");
+    return restower_x3_launch(packed, bias, x, y, n, 0, stream, (long long *)stamps);
 }
 
 static int launch_tower(const char *who, const mz_tower_weights *w, const mz_heads_weights *hw, const void *x, void *hidden,

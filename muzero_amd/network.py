@@ -222,27 +222,31 @@ class InferenceEngine:
 
     # ---- split-precision tower (fp32 serving) ------------------------------------------------------
     def _repack_x3(self):
-        """the residual blocks' weight stream (hi, hi, lo per convolution) and their six biases, (re)built IN PLACE (a captured
-        hipGraph holds their addresses)"""
-        from .convgrad import restower_x3_pack
-        for name, (_first, blocks, _last, _cin) in self._tower_parts().items():
+        """the towers in split precision: the residual blocks' weight stream (hi, lo per convolution), the first / last convolutions'
+        fragments and the biases, (re)built IN PLACE (a captured hipGraph holds their addresses)"""
+        from .convgrad import restower_x3_pack, tower_x3_pack_ends
+        for name, (first, blocks, last, _cin) in self._tower_parts().items():
             convs = [blk.block[ci] for blk in blocks for ci in (0, 2)]
             if name not in self._packs3:
-                self._packs3[name] = (restower_x3_pack([c.weight for c in convs]), torch.empty((6, 128), dtype=torch.float32, device=self.device))
-            packed, bias = self._packs3[name]
+                f32 = lambda k: torch.empty(k, dtype=torch.float32, device=self.device)  # noqa: E731
+                self._packs3[name] = (restower_x3_pack([c.weight for c in convs]), tower_x3_pack_ends(first.weight, last.weight), f32((6, 128)),
+                                      None if first.bias is None else f32(128), None if last.bias is None else f32(8))
+            packed, ends, bias, b_first, b_last = self._packs3[name]
             restower_x3_pack([c.weight for c in convs], out=packed)
+            tower_x3_pack_ends(first.weight, last.weight, out=ends)
             for i, c in enumerate(convs):
                 bias[i].copy_(c.bias.detach())
+            if b_first is not None:
+                b_first.copy_(first.bias.detach())
+            if b_last is not None:
+                b_last.copy_(last.bias.detach())
 
     def _tower_x3(self, name, x):
-        """first and last convolution through PyTorch/MIOpen in fp32; between them the three residual blocks as ONE LDS-resident
-        launch in split precision (the first convolution's ReLU is applied on load, the result overwrites its output)"""
-        from .convgrad import restower_x3
-        first, _blocks, last, _cin = self._tower_parts()[name]
-        packed, bias = self._packs3[name]
-        y = F.conv2d(x.contiguous(), first.weight, first.bias, 1, 1)
-        restower_x3(y, packed, bias, relu_in=True, out=y)
-        return F.relu(F.conv2d(y, last.weight, last.bias, 1, 1))
+        """the whole tower -- first convolution, three residual blocks, last convolution -- as ONE LDS-resident launch in split
+        precision (mz_tower_x3_forward): planes in, hidden state out"""
+        from .convgrad import tower_x3
+        packed, ends, bias, b_first, b_last = self._packs3[name]
+        return tower_x3(x.contiguous(), packed, ends, bias, b_first, b_last)
 
     # ---- HIP tower ---------------------------------------------------------------------------------
     def _tower_parts(self):

@@ -218,6 +218,37 @@ def test_split_precision_residual_tower_matches_fp64(n):
     assert torch.equal(restower_x3(x, packed, bias), restower_x3(x, restower_x3_pack(ws2), bias))
 
 
+@pytest.mark.parametrize("n,cin,with_bias", [(1, 9, True), (7, 10, False), (64, 10, False), (1030, 9, True), (33, 16, True), (5, 1, False)])
+def test_split_precision_whole_tower_matches_fp64(n, cin, with_bias):
+    """mz_tower_x3_forward: first convolution (cin -> 128), three residual blocks, last convolution (128 -> 8) -- Representation
+    (network.py:49-77, 9 planes, biases) and Dynamics (network.py:113-135, 10 planes, no bias on the ends) -- in ONE launch,
+    against the fp64 modules"""
+    from muzero_amd.convgrad import restower_x3_pack, tower_x3, tower_x3_pack_ends
+    g = torch.Generator(device="cuda").manual_seed(7 * n + cin)
+    ws = [torch.randn(128, 128, 3, 3, device="cuda", generator=g) * 0.03 for _ in range(6)]
+    bias = torch.randn(6, 128, device="cuda", generator=g) * 0.2
+    wf = torch.randn(128, cin, 3, 3, device="cuda", generator=g) * 0.2
+    wl = torch.randn(8, 128, 3, 3, device="cuda", generator=g) * 0.03
+    bf = torch.randn(128, device="cuda", generator=g) * 0.2 if with_bias else None
+    bl = torch.randn(8, device="cuda", generator=g) * 0.2 if with_bias else None
+    x = torch.rand(n, cin, 8, 8, device="cuda", generator=g)
+    F = torch.nn.functional
+    d = lambda t: None if t is None else t.double()  # noqa: E731
+    h = F.conv2d(x.double(), wf.double(), d(bf), padding=1).relu()
+    for blk in range(3):
+        t = F.conv2d(h, ws[2 * blk].double(), bias[2 * blk].double(), padding=1).relu()
+        h = (h + F.conv2d(t, ws[2 * blk + 1].double(), bias[2 * blk + 1].double(), padding=1)).relu()
+    want = F.conv2d(h, wl.double(), d(bl), padding=1).relu()
+    packed, ends = restower_x3_pack(ws), tower_x3_pack_ends(wf, wl)
+    got = tower_x3(x, packed, ends, bias, bf, bl)
+    assert got.shape == (n, 8, 8, 8) and got.dtype == torch.float32
+    err = (got.double() - want).norm().item() / want.norm().item()
+    print("whole tower, %d boards, %d planes: relative L2 error %.3g, max %.3g of max %.3g" % (n, cin, err, (got.double() - want).abs().max().item(), want.abs().max().item()))
+    assert err <= 2e-5
+    assert (got.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    assert torch.equal(tower_x3(x, packed, ends, bias, bf, bl), got)
+
+
 def test_training_gradients_in_split_precision_match_the_fp32_step():
     """the K = 5 unrolled loss with the towers in split precision against the fp32 PyTorch/MIOpen step (itself Winograd
     arithmetic, not exact sums): measured on MI355X worst tensor 1.0e-3, median 1.7e-4 -- 50-90 x closer than the one-product
