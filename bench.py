@@ -683,10 +683,10 @@ def main():
                     value=n * S / dtx, unit="simulations/s", ms_per_step=dtx * 1e3, steps=args.fp32_steps,
                     inference="fp32 serving: each tower (first convolution, three residual blocks, last convolution) as ONE LDS-resident launch in "
                               "split precision (k_restower_x3: hi / lo bf16 activation images, three bf16 MFMA products per fp32 product, fp32 sums, "
-                              "skip path in fp32 registers), heads through PyTorch fp32",
+                              "skip path in fp32 registers) with the prediction heads in plain fp32 behind it (mz_inference_x3_forward)",
                     roofline={"bound": "mfma", "achieved": 3 * tfx, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3 * tfx / BF16_PEAK_TFLOPS,
                               "us_per_launch_sequence": msx * 1e3, "fp32_grade_tflops": tfx,
-                              "note": "bf16 MFMA work = 3 x the network's FLOPs, over the whole recurrent inference call (tower launch + heads)"},
+                              "note": "bf16 MFMA work = 3 x the network's FLOPs, one launch per inference (tower + heads)"},
                     agreement_with_fp32_search=visit_agreement(fp32_visits, x3_visits))
                 del engx, netx
             except Exception as e:   # noqa: BLE001  (optional leg)

@@ -500,6 +500,11 @@ int mz_restower_x3_forward(const void *packed, const float *bias, const float *x
 int mz_tower_x3_pack_ends(const float *w_first, int32_t cin, const float *w_last, void *ends, void *stream);
 int mz_tower_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
                         const float *x, float *hidden, int64_t n, void *stream);
+/* initial_inference / recurrent_inference (network.py:146-163) at fp32 grade in ONE launch: mz_tower_x3_forward + the prediction
+ * heads in plain fp32 behind it.  heads: mz_heads_weights whose p1_w / p2_w are F32 [out][in] matrices here (nn.Linear's own
+ * tensors), 16-byte aligned.  value (n) f32, policy (n,65) f32 softmaxed, hidden (n,8,8,8) f32. */
+int mz_inference_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                            const mz_heads_weights *heads, const float *x, float *hidden, float *value, float *policy, int64_t n, void *stream);
 /* diagnostics: the same launch (relu_in = 0) writing shader-cycle stamps at the phase boundaries of every 4-board tile into
  * stamps, (ceil(n / 4), 32) int64 on the device (tools/restower_stamps.py reads them) */
 int mz_restower_x3_stamps(const void *packed, const float *bias, const float *x, float *y, int64_t n, void *stamps, void *stream);

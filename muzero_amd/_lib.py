@@ -119,6 +119,7 @@ SIGNATURES = {
     "mz_restower_x3_stamps": [_p, _p, _p, _p, _i64, _p, _p],
     "mz_tower_x3_pack_ends": [_p, _i32, _p, _p, _p],
     "mz_tower_x3_forward": [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p],
+    "mz_inference_x3_forward": [_p, _p, _p, _p, _p, _i32, C.POINTER(HeadsWeights), _p, _p, _p, _p, _i64, _p],
 }
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)

@@ -968,7 +968,13 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
 struct ResArgs {
     const uint4 *w; const float *bias; const float *x; float *y; int64_t n_boards; int relu_in; long long *stamps;
     const uint16_t *ends; const float *b_first; const float *b_last; int cin;   // FULL only
+    // FULL, optional (value != null): the prediction heads (network.py:79-111) behind the tower in plain fp32 on the VALU -- 25k MACs
+    // per board are nothing beside the tower's 3 x 58 M -- with the Linear matrices as f32 [out][in] (nn.Linear's layout)
+    const float *pc_w, *pc_b, *p1_w, *p1_b, *p2_w, *p2_b, *vc_w, *vc_b, *v1_w, *v1_b;
+    float *value, *policy;
 };
+constexpr int X3_HEADS_OFF = 81920;   // heads scratch in LDS, behind the last layer's partial sums (4 x P_WAVE_BYTES = 73,728)
+static_assert(4 * P_WAVE_BYTES <= X3_HEADS_OFF && X3_HEADS_OFF + (2048 + 3 * 512 + 4 * 80) * 4 <= LDS_BYTES, "heads scratch");
 // ends = the two small convolutions' MFMA fragments, read straight from global memory (L2-resident, the same for every tile):
 //   first: [2 parts][5 k-steps][128 co][32] bf16, k = 16 t2 + c -> tap 2 ks + t2, input plane c (zero beyond tap 8 / plane cin - 1)
 //   last : [2 parts][4 quarters][80 rows][32 ci] bf16, row = tap * 8 + plane (72 real)          part 0 = bf16 rounding, 1 = remainder
@@ -1181,9 +1187,76 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
                     s1 += p1;
                 }
             }
-            if (live) {
+            float *hid = reinterpret_cast<float *>(lds + X3_HEADS_OFF);   // [4 boards][8 planes][64 cells]
 #pragma unroll
-                for (int k = 0; k < 8; ++k) a.y[b * 512 + k * 64 + lane] = fmaxf(k < 4 ? s0[k & 3] : s1[k & 3], 0.0f);
+            for (int k = 0; k < 8; ++k) {
+                const float hv = fmaxf(k < 4 ? s0[k & 3] : s1[k & 3], 0.0f);
+                if (live) a.y[b * 512 + k * 64 + lane] = hv;
+                if (a.value) hid[(w >> 1) * 512 + k * 64 + lane] = hv;
+            }
+        }
+        if (a.value) {   // heads: thread = (board tid >> 7, feature / output tid & 127)
+            float *hid = reinterpret_cast<float *>(lds + X3_HEADS_OFF);
+            float *fp = hid + 2048, *fv = fp + 512, *h1 = fv + 512, *lg = h1 + 512;   // [4][128] x 3, logits [4][80]
+            const int hb = tid >> 7, k = tid & 127;
+            __syncthreads();
+            {   // 1x1 convolutions 8 -> 2 + ReLU, flattened channel-major (nn.Flatten of (2,8,8))
+                const int c2 = k >> 6, pos = k & 63;
+                float ap = a.pc_b[c2], av = a.vc_b[c2];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xv = hid[hb * 512 + c * 64 + pos];
+                    ap += a.pc_w[c2 * 8 + c] * xv;
+                    av += a.vc_w[c2 * 8 + c] * xv;
+                }
+                fp[tid] = fmaxf(ap, 0.0f);
+                fv[tid] = fmaxf(av, 0.0f);
+            }
+            __syncthreads();
+            {   // Linear(128,128) + ReLU
+                float s = a.p1_b[k];
+                const f32x4 *row = reinterpret_cast<const f32x4 *>(a.p1_w + k * 128);
+                const f32x4 *f = reinterpret_cast<const f32x4 *>(fp + hb * 128);
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) {
+                    const f32x4 wv = row[i], xv = f[i];
+                    s += wv[0] * xv[0];
+                    s += wv[1] * xv[1];
+                    s += wv[2] * xv[2];
+                    s += wv[3] * xv[3];
+                }
+                h1[tid] = fmaxf(s, 0.0f);
+            }
+            if (tid < 4) {   // value: Linear(128,1) + tanh
+                float s = a.v1_b[0];
+                for (int i = 0; i < 128; ++i) s += a.v1_w[i] * fv[tid * 128 + i];
+                if (board0 + tid < a.n_boards) a.value[board0 + tid] = tanhf(s);
+            }
+            __syncthreads();
+            if (k < MZ_ACTIONS) {   // Linear(128,65)
+                float s = a.p2_b[k];
+                const f32x4 *row = reinterpret_cast<const f32x4 *>(a.p2_w + k * 128);
+                const f32x4 *f = reinterpret_cast<const f32x4 *>(h1 + hb * 128);
+#pragma unroll 8
+                for (int i = 0; i < 32; ++i) {
+                    const f32x4 wv = row[i], xv = f[i];
+                    s += wv[0] * xv[0];
+                    s += wv[1] * xv[1];
+                    s += wv[2] * xv[2];
+                    s += wv[3] * xv[3];
+                }
+                lg[hb * 80 + k] = s;
+            }
+            __syncthreads();
+            if (w < 4) {   // softmax over the 65 logits of board w: lane -> action, lane 0 also action 64
+                const float l0 = lg[w * 80 + lane], l1 = lane == 0 ? lg[w * 80 + 64] : -INFINITY;
+                const float m = wave_max_dpp(fmaxf(l0, l1));
+                const float e0 = expf(l0 - m), e1 = lane == 0 ? expf(l1 - m) : 0.0f;
+                const float tot = wave_sum_dpp(e0 + e1);
+                if (board0 + w < a.n_boards) {
+                    a.policy[(board0 + w) * MZ_ACTIONS + lane] = e0 / tot;
+                    if (lane == 0) a.policy[(board0 + w) * MZ_ACTIONS + 64] = e1 / tot;
+                }
             }
         }
     } else if (live) {
@@ -1356,8 +1429,8 @@ extern "C" int mz_tower_x3_pack_ends(const float *w_first, int32_t cin, const fl
     return MZ_OK;
 }
 
-extern "C" int mz_tower_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
-                                  const float *x, float *hidden, int64_t n, void *stream) {
+static int tower_x3_launch(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                           const mz_heads_weights *hw, const float *x, float *hidden, float *value, float *policy, int64_t n, void *stream) {
     MZ_REQUIRE(n >= 0, "mz_tower_x3_forward: n < 0");
     if (n == 0) return MZ_OK;
     MZ_REQUIRE(packed && ends && bias && x && hidden, "mz_tower_x3_forward: null pointer");
@@ -1367,10 +1440,29 @@ extern "C" int mz_tower_x3_forward(const void *packed, const void *ends, const f
     MZ_REQUIRE((const void *)x != (const void *)hidden, "mz_tower_x3_forward: in-place call");
     const int64_t n_tiles = (n + 3) / 4;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_tower_x3_forward: too many boards");
-    const ResArgs a{(const uint4 *)packed, bias, x, hidden, n, 0, nullptr, (const uint16_t *)ends, b_first, b_last, (int)cin};
+    ResArgs a{(const uint4 *)packed, bias, x, hidden, n, 0, nullptr, (const uint16_t *)ends, b_first, b_last, (int)cin,
+              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (hw) {
+        MZ_REQUIRE(hw->pc_w && hw->pc_b && hw->p1_w && hw->p1_b && hw->p2_w && hw->p2_b && hw->vc_w && hw->vc_b && hw->v1_w && hw->v1_b && value && policy,
+                   "mz_inference_x3_forward: null head pointer");
+        MZ_REQUIRE((((uintptr_t)hw->p1_w | (uintptr_t)hw->p2_w) & 15) == 0, "mz_inference_x3_forward: heads p1_w / p2_w must be 16-byte aligned");
+        a.pc_w = hw->pc_w; a.pc_b = hw->pc_b; a.p1_w = (const float *)hw->p1_w; a.p1_b = hw->p1_b; a.p2_w = (const float *)hw->p2_w; a.p2_b = hw->p2_b;
+        a.vc_w = hw->vc_w; a.vc_b = hw->vc_b; a.v1_w = hw->v1_w; a.v1_b = hw->v1_b; a.value = value; a.policy = policy;
+    }
     hipLaunchKernelGGL(k_restower_x3<true>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_restower_x3<full>");
     return MZ_OK;
+}
+
+extern "C" int mz_tower_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                                  const float *x, float *hidden, int64_t n, void *stream) {
+    return tower_x3_launch(packed, ends, bias, b_first, b_last, cin, nullptr, x, hidden, nullptr, nullptr, n, stream);
+}
+
+extern "C" int mz_inference_x3_forward(const void *packed, const void *ends, const float *bias, const float *b_first, const float *b_last, int32_t cin,
+                                      const mz_heads_weights *heads, const float *x, float *hidden, float *value, float *policy, int64_t n, void *stream) {
+    MZ_REQUIRE(heads, "mz_inference_x3_forward: null heads");
+    return tower_x3_launch(packed, ends, bias, b_first, b_last, cin, heads, x, hidden, value, policy, n, stream);
 }
 
 static int restower_x3_launch(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu_in, void *stream, long long *stamps) {
@@ -1381,7 +1473,8 @@ static int restower_x3_launch(const void *packed, const float *bias, const float
     MZ_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 3) == 0, "mz_restower_x3_forward: x and y must be f32 tensors");
     const int64_t n_tiles = (n + 3) / 4;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_restower_x3_forward: too many boards");
-    const ResArgs a{(const uint4 *)packed, bias, x, y, n, relu_in ? 1 : 0, stamps, nullptr, nullptr, nullptr, 0};
+    ResArgs a{};
+    a.w = (const uint4 *)packed; a.bias = bias; a.x = x; a.y = y; a.n_boards = n; a.relu_in = relu_in ? 1 : 0; a.stamps = stamps;
     hipLaunchKernelGGL(k_restower_x3<false>, dim3((unsigned)n_tiles), dim3(512), 0, (hipStream_t)stream, a);
     MZ_LAUNCH_CHECK("k_restower_x3");
     return MZ_OK;

@@ -240,6 +240,20 @@ class InferenceEngine:
                 b_first.copy_(first.bias.detach())
             if b_last is not None:
                 b_last.copy_(last.bias.detach())
+        # the prediction heads in fp32 (the Linear matrices as nn.Linear holds them), copies refilled in place
+        from . import _lib as L
+        ph, vh = self.net.prediction.policy_head, self.net.prediction.value_head
+        f = lambda t: t.detach().float().contiguous()  # noqa: E731
+        heads = dict(pc_w=f(ph[0].weight.reshape(2, 8)), pc_b=f(ph[0].bias), p1_w=f(ph[3].weight), p1_b=f(ph[3].bias),
+                     p2_w=f(ph[5].weight), p2_b=f(ph[5].bias), vc_w=f(vh[0].weight.reshape(2, 8)), vc_b=f(vh[0].bias),
+                     v1_w=f(vh[3].weight.reshape(128)), v1_b=f(vh[3].bias))
+        if "heads" not in self._packs3:
+            heads = {k: t.clone() for k, t in heads.items()}
+            heads["struct"] = L.HeadsWeights(*[heads[k].data_ptr() for k, _ in L.HeadsWeights._fields_])
+            self._packs3["heads"] = heads
+        else:
+            for k, t in heads.items():
+                self._packs3["heads"][k].copy_(t)
 
     def _tower_x3(self, name, x):
         """the whole tower -- first convolution, three residual blocks, last convolution -- as ONE LDS-resident launch in split
@@ -247,6 +261,23 @@ class InferenceEngine:
         from .convgrad import tower_x3
         packed, ends, bias, b_first, b_last = self._packs3[name]
         return tower_x3(x.contiguous(), packed, ends, bias, b_first, b_last)
+
+    def _infer_x3(self, name, x):
+        """network.initial_inference / recurrent_inference (network.py:146-163) at fp32 grade in ONE launch: the tower in split
+        precision and the heads in plain fp32 behind it (mz_inference_x3_forward)"""
+        from . import _lib as L
+        packed, ends, bias, b_first, b_last = self._packs3[name]
+        x = x.contiguous()
+        cin = self._tower_parts()[name][3]
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or tuple(x.shape[1:]) != (cin, 8, 8):
+            raise L.MzError("hip_x3 input must be a cuda float32 (n,%d,8,8) tensor, got %s %s" % (cin, tuple(x.shape), x.dtype))
+        n = x.shape[0]
+        hidden = torch.empty((n, HIDDEN_PLANES, 8, 8), dtype=torch.float32, device=x.device)
+        value = torch.empty((n,), dtype=torch.float32, device=x.device)
+        policy = torch.empty((n, config.action_space_size), dtype=torch.float32, device=x.device)
+        L.call("mz_inference_x3_forward", L.dptr(packed), L.dptr(ends), L.dptr(bias), L.dptr(b_first), L.dptr(b_last), cin,
+               L.C.byref(self._packs3["heads"]["struct"]), L.dptr(x), L.dptr(hidden), L.dptr(value), L.dptr(policy), n, L.current_stream())
+        return value, policy, hidden
 
     # ---- HIP tower ---------------------------------------------------------------------------------
     def _tower_parts(self):
@@ -406,10 +437,14 @@ class InferenceEngine:
         """out: see output_buffers() (HIP path only; the MIOpen path returns what PyTorch allocates)"""
         if self.tower == "hip":
             return self._infer_hip("repr", image.to(self.dtype), out)
+        if self.tower == "hip_x3":
+            return self._infer_x3("repr", image.to(self.dtype))
         return self._finish(self._hidden_initial(image.to(self.dtype)))
 
     @torch.no_grad()
     def recurrent(self, x10, out=None):
         if self.tower == "hip":
             return self._infer_hip("dyn", x10, out)
+        if self.tower == "hip_x3":
+            return self._infer_x3("dyn", x10)
         return self._finish(self._hidden_recurrent(x10))
