@@ -37,14 +37,16 @@ from . import train as T
 
 class MuZeroLoop:
     def __init__(self, games_per_rank, device="cuda", infer_dtype=torch.bfloat16, num_simulations=None, window_size=None,
-                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated", train_convs="fp32"):
+                 batch_size=None, seed=1261, use_graph=True, group=None, replay_mode="replicated", train_convs="fp32", infer_tower="auto"):
         """replay_mode "replicated": trajectories are all_gathered and every rank holds the whole window (what
         BASELINE configs[3] describes); "sharded": no gather at all -- every rank keeps only the games it played (1/N of the
         window), all ranks make the same global draws and each trains on the draws that hit its own games, with the
         gradient all-reduce weighted by the local batch sizes.  Both train on exactly the batch one process would draw.
         train_convs "fp32": the reference's arithmetic (PyTorch/MIOpen); "hip": the towers' 128 -> 128 convolutions and their
         gradients on the hand-written matrix-core kernels (bf16 operands, fp32 sums and master weights: train.update_weights
-        hip_convs); "hip_x3": those kernels in split precision (three bf16 products per fp32 product: close to fp32)."""
+        hip_convs); "hip_x3": those kernels in split precision (three bf16 products per fp32 product: close to fp32).
+        infer_tower: InferenceEngine's tower ("auto": the bf16 HIP kernel for infer_dtype bf16; "hip_x3" with infer_dtype float32:
+        self-play at the reference's fp32 precision on the split-precision tower kernel)."""
         self.group = group
         self.world = dist.get_world_size(group) if T._dist_on(group) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -56,7 +58,8 @@ class MuZeroLoop:
         self.optimizer = T.make_optimizer(self.network)
         self.bucket = T.FlatGradBucket(self.network.parameters())
         self.storage = T.SharedStorage(self.network.state_dict())
-        self.infer = InferenceEngine(self.network, games_per_rank, infer_dtype, device=self.device)   # serves its own copy
+        self.infer = InferenceEngine(self.network, games_per_rank, infer_dtype, device=self.device, tower=infer_tower,
+                                     channels_last=infer_tower != "hip_x3")   # serves its own copy
         self.selfplay = SelfPlayEngine(games_per_rank, self.infer, num_simulations=num_simulations, device=self.device,
                                        use_graph=use_graph, seed=seed + 7919 * self.rank)
         self.batch_size = int(batch_size if batch_size is not None else config.batch_size)

@@ -1,10 +1,11 @@
 """The whole MuZero loop on one GPU, end to end: G generations of (self-play -> replay window -> training -> publish),
 then the arena: trained network vs the initial one.
-python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax] [fp32|hip|hip_x3]
+python tools/run_loop.py [generations] [train_steps] [games] [lr weight_decay] [negamax] [fp32|hip|hip_x3] [bf16|x3]
 Without lr/weight_decay the optimiser is the reference's (main.py:206: lr 1e-3, weight_decay 0.1 -- it hardly learns in
 a short run); give both to see the loop learn.  negamax = 1 sets config.negamax_value (non-default: the search maximises
 the mover's own value instead of the reference's child-mover value).  hip / hip_x3: the training step's tower convolutions on
-the hand-written kernels (bf16 / split precision)."""
+the hand-written kernels (bf16 / split precision).  Last argument x3: self-play serves fp32 on the split-precision tower kernel
+(InferenceEngine(tower="hip_x3")) instead of bf16."""
 import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +23,10 @@ if len(sys.argv) > 6 and int(sys.argv[6]):
     print("config.negamax_value = True")
 convs = sys.argv[7] if len(sys.argv) > 7 else "fp32"
 print("training convolutions: %s" % convs)
-lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512, train_convs=convs)
+serve = sys.argv[8] if len(sys.argv) > 8 else "bf16"
+print("self-play inference: %s" % serve)
+lp = MuZeroLoop(games, num_simulations=50, window_size=4 * games, batch_size=512, train_convs=convs,
+                **(dict(infer_dtype=torch.float32, infer_tower="hip_x3") if serve == "x3" else {}))
 init = copy.deepcopy(lp.network.state_dict())
 if len(sys.argv) > 5:
     lp.optimizer = torch.optim.SGD(lp.network.parameters(), lr=float(sys.argv[4]), momentum=config.momentum, weight_decay=float(sys.argv[5]))
