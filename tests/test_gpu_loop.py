@@ -55,6 +55,29 @@ def test_generations_with_hip_training_convolutions():
         config.num_unroll_steps = old
 
 
+def test_generation_at_fp32_grade():
+    """infer_tower="hip_x3" + train_convs="hip_x3": self-play served by the split-precision tower kernel (fp32 hidden-state pool)
+    and the training step on the split-precision kernels -- the reference's fp32 arithmetic to ~1e-5 at every step; the first
+    generation's losses follow the fp32 loop's (bf16 self-play plays other games, so the fp32 MIOpen engine is the partner)"""
+    from muzero_amd import config
+    from muzero_amd.loop import MuZeroLoop
+    old = config.num_unroll_steps
+    config.num_unroll_steps = 5
+    try:
+        out = {}
+        for mode, kw in (("miopen", dict(infer_tower="miopen", train_convs="fp32")), ("x3", dict(infer_tower="hip_x3", train_convs="hip_x3"))):
+            loop = MuZeroLoop(64, num_simulations=6, window_size=64, batch_size=32, infer_dtype=torch.float32, **kw)
+            out[mode] = [(float(p), float(v)) for p, v in loop.generation(4)]
+            assert loop.replay.buffer_size == 64 and loop.network.steps == 4
+            for a, b in zip(loop.infer.net.state_dict().values(), loop.network.state_dict().values()):
+                assert a.dtype == torch.float32 and torch.equal(a, b)
+        a, b = np.array(out["miopen"]), np.array(out["x3"])
+        assert np.isfinite(b).all()
+        assert np.allclose(a, b, rtol=2e-2), (a, b)
+    finally:
+        config.num_unroll_steps = old
+
+
 def test_sharded_window_equals_replicated_on_one_rank():
     """replay_mode="sharded" (no trajectory gather, local batches weighted in the all-reduce) makes the same draws and the
     same updates as the replicated window; with one rank the two must agree exactly"""
