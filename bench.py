@@ -507,6 +507,42 @@ def main():
                    "trees_per_gpu": n, "simulations": S, "hipgraph": not args.no_graph, "parallelism": "games sharded x%d" % world},
     }
 
+    def tower_roofline():
+        # ---- the dominant kernel of the timed region: the inference launch (k_tower: conv tower + heads, ~97 % of a
+        # simulation step), HIP-event timed back to back on the launch stream; MFMA bound
+        # (into one reused set of output buffers, as the timed search runs it)
+        net_out = net.output_buffers(n) if getattr(net, "tower", "") == "hip" else None
+        if net_out is not None and not args.no_graph:
+            # 25 launches captured in one hipGraph, as the timed search replays them (eager launches from Python leave a gap of
+            # ~20 us between dependent kernels that the graph does not have)
+            sg = torch.cuda.Stream(device=device)
+            sg.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sg):
+                net.recurrent(eng.mcts.net_in, out=net_out)
+            torch.cuda.current_stream().wait_stream(sg)
+            torch.cuda.synchronize()
+            tg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tg):
+                for _ in range(25):
+                    net.recurrent(eng.mcts.net_in, out=net_out)
+            ms_net = event_time_ms(tg.replay, 4) / 25
+        else:
+            ms_net = event_time_ms((lambda: net.recurrent(eng.mcts.net_in, out=net_out)) if net_out is not None else (lambda: net.recurrent(eng.mcts.net_in)), 50)
+        peak = F32_PEAK_TFLOPS if dtype == torch.float32 else BF16_PEAK_TFLOPS
+        hip = getattr(net, "tower", "") == "hip"
+        flop = n * (TOWER_FLOP if hip else NET_MFLOP * 1e6)
+        tf = flop / (ms_net * 1e-3) / 1e12
+        return {"kernel": "k_tower (mz_inference_forward: LDS-resident conv tower + prediction heads)" if hip else
+                           "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf, "peak": peak,
+                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": pmc_traffic("k_tower") if hip else None, "traffic_source": pmc_traffic_src("k_tower")[1] if hip else None,
+                           "us_per_launch": ms_net * 1e3, "boards_per_launch": n, "flop_per_board": TOWER_FLOP if hip else NET_MFLOP * 1e6,
+                           "algorithmic_flop_per_launch": flop, "share_of_step": ms_net / (dt / args.steps / S * 1e3)}
+
+    if rank == 0 and world > 1:   # the dominant kernel's roofline on rank 0 (the other legs are N = 1 only); the other ranks wait at the last barrier
+        try:
+            out["roofline"] = tower_roofline()
+        except Exception as e:   # noqa: BLE001
+            out["roofline_error"] = "%s: %s" % (type(e).__name__, e)
     if rank == 0 and world == 1 and not args.skip_extras:
         # ---- roofline of the dominant hand-written kernel: k_backup_select, HIP-event timed on the launch stream
         from muzero_amd import _lib as L
@@ -564,35 +600,7 @@ def main():
                                         "profiles/r02/tree_experiment_latency.txt",
                                 "valu_static": {k: (kernel_isa("k_backup_select") or {}).get(k) for k in
                                                 ("valu_instructions", "fp64_valu_instructions", "salu_instructions", "vmem_instructions", "has_loop")}}
-        # ---- the dominant kernel of the timed region: the inference launch (k_tower: conv tower + heads, ~97 % of a
-        # simulation step), HIP-event timed back to back on the launch stream; MFMA bound
-        # (into one reused set of output buffers, as the timed search runs it)
-        net_out = net.output_buffers(n) if getattr(net, "tower", "") == "hip" else None
-        if net_out is not None and not args.no_graph:
-            # 25 launches captured in one hipGraph, as the timed search replays them (eager launches from Python leave a gap of
-            # ~20 us between dependent kernels that the graph does not have)
-            sg = torch.cuda.Stream(device=device)
-            sg.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(sg):
-                net.recurrent(eng.mcts.net_in, out=net_out)
-            torch.cuda.current_stream().wait_stream(sg)
-            torch.cuda.synchronize()
-            tg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tg):
-                for _ in range(25):
-                    net.recurrent(eng.mcts.net_in, out=net_out)
-            ms_net = event_time_ms(tg.replay, 4) / 25
-        else:
-            ms_net = event_time_ms((lambda: net.recurrent(eng.mcts.net_in, out=net_out)) if net_out is not None else (lambda: net.recurrent(eng.mcts.net_in)), 50)
-        peak = F32_PEAK_TFLOPS if dtype == torch.float32 else BF16_PEAK_TFLOPS
-        hip = getattr(net, "tower", "") == "hip"
-        flop = n * (TOWER_FLOP if hip else NET_MFLOP * 1e6)
-        tf = flop / (ms_net * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_tower (mz_inference_forward: LDS-resident conv tower + prediction heads)" if hip else
-                           "recurrent_inference (MIOpen/hipBLASLt via PyTorch)", "bound": "mfma", "achieved": tf, "peak": peak,
-                           "unit": "TFLOP/s", "frac": tf / peak, "traffic": pmc_traffic("k_tower") if hip else None, "traffic_source": pmc_traffic_src("k_tower")[1] if hip else None,
-                           "us_per_launch": ms_net * 1e3, "boards_per_launch": n, "flop_per_board": TOWER_FLOP if hip else NET_MFLOP * 1e6,
-                           "algorithmic_flop_per_launch": flop, "share_of_step": ms_net / (dt / args.steps / S * 1e3)}
+        out["roofline"] = tower_roofline()
         out.update(bench_env(args, device))
         if args.selfplay_games > 0:
             g = args.selfplay_games
