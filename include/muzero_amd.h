@@ -457,7 +457,7 @@ int mz_conv3x3_wgrad(const float *const *x, const float *const *g, const int64_t
 int mz_conv3x3_pack(const float *w, void *packed_fwd, void *packed_bwd, void *stream);
 int mz_conv3x3_forward(const void *packed, const float *bias, const float *x, float *y, int64_t n, int32_t relu, void *stream);
 /* mz_conv3x3_forward with the residual block's elementwise work fused into the store phase (all tensors (n,128,8,8) f32 NCHW,
- * skip / mask nullable, mask may not alias y; x_part 0 = x rounded to bf16, 1 = see split precision below):
+ * skip / mask nullable, mask may not alias y; x_part 0 = x rounded to bf16, 1 / 2 = see split precision below):
  *     y = [relu]( [mask > 0 ?] (conv(x) + bias [+ skip]) : 0 )
  *   forward : t = relu(conv1(h))             -> relu = 1
  *             y = relu(h + conv2(t))         -> skip = h, relu = 1                                   (network.py:35-47)
@@ -472,6 +472,9 @@ int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, int3
  *   mz_conv3x3_pack_part(part = 1) packs the weights' lo images; x_part = 1 makes mz_conv3x3_fused convolve the lo part of x.
  *   One convolution = three launches accumulating through skip (which may alias y):
  *       y  = conv(x hi, W hi) + bias [+ residual skip];   y += conv(x lo, W hi);   y = epilogue(y + conv(x hi, W lo))
+ *   or ONE launch, x_part = 2: packed then points at a stream [36 stages of the hi image][36 of the lo image][4 of padding] (pack the
+ *   hi image to p, then the lo image to p + 36 * 4096 * 2 bytes); x goes into a hi and a lo image in LDS (4-board tiles), W_hi meets
+ *   both in one K loop, W_lo x_hi follows, the epilogue runs once.
  *   mz_conv3x3_wgrad_x3 forms the three products inside one pass over the operands. */
 int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream);
 /* the same for up to 16 convolutions in ONE launch (a training step repacks all twelve): w, packed_fwd, packed_bwd are HOST arrays of n pointers */

@@ -64,13 +64,27 @@ def pack_conv(weight, out=None, split=False):
     w = weight.detach()
     if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
         raise L.MzError("pack_conv: need a contiguous cuda float32 (128,128,3,3) weight")
-    if out is None:
-        out = torch.empty((4 if split else 2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
-    L.call("mz_conv3x3_pack", L.dptr(w), L.dptr(out[0]), L.dptr(out[1]), L.current_stream())
     if not split:
+        if out is None:
+            out = torch.empty((2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
+        L.call("mz_conv3x3_pack", L.dptr(w), L.dptr(out[0]), L.dptr(out[1]), L.current_stream())
         return out[0], out[1]
-    L.call("mz_conv3x3_pack_part", L.dptr(w), L.dptr(out[2]), L.dptr(out[3]), 1, L.current_stream())
-    return out[0], out[1], out[2], out[3]
+    if out is None:
+        out = torch.empty((2, STREAM_ELEMS), dtype=torch.bfloat16, device=w.device)
+    views = _stream_views(out)
+    L.call("mz_conv3x3_pack", L.dptr(w), L.dptr(views[0]), L.dptr(views[1]), L.current_stream())          # hi, + 4 zero stages ...
+    L.call("mz_conv3x3_pack_part", L.dptr(w), L.dptr(views[2]), L.dptr(views[3]), 1, L.current_stream())   # ... that the lo image overwrites
+    return views
+
+
+STREAM_ELEMS = 76 * 4096   # split precision: [36 stages hi][36 stages lo][4 stages of padding] per direction
+
+
+def _stream_views(buf):
+    """(2, STREAM_ELEMS) -> (forward hi, data-gradient hi, forward lo, data-gradient lo), 40-stage views: a hi view's padding
+    stages are the lo image's first stages (prefetched, never used), and hi + lo together are the stream one split-precision
+    launch walks (mz_conv3x3_fused x_part = 2)"""
+    return buf[0, :PACKED_ELEMS], buf[1, :PACKED_ELEMS], buf[0, 36 * 4096:], buf[1, 36 * 4096:]
 
 
 def pack_convs(weights, split=False):
@@ -82,20 +96,26 @@ def pack_convs(weights, split=False):
         if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
             raise L.MzError("pack_convs: need contiguous cuda float32 (128,128,3,3) weights")
     k = len(ws)
-    out = torch.empty((k, 4 if split else 2, PACKED_ELEMS), dtype=torch.bfloat16, device=ws[0].device)
     wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
-    for part in ((0, 1) if split else (0,)):
-        fp = (C.c_void_p * k)(*[out[i, 2 * part].data_ptr() for i in range(k)])
-        bp = (C.c_void_p * k)(*[out[i, 2 * part + 1].data_ptr() for i in range(k)])
+    if split:
+        out = torch.empty((k, 2, STREAM_ELEMS), dtype=torch.bfloat16, device=ws[0].device)
+        res = [_stream_views(out[i]) for i in range(k)]
+    else:
+        out = torch.empty((k, 2, PACKED_ELEMS), dtype=torch.bfloat16, device=ws[0].device)
+        res = [(out[i, 0], out[i, 1]) for i in range(k)]
+    for part in ((0, 1) if split else (0,)):   # hi first: its zero padding stages are where the lo image starts
+        fp = (C.c_void_p * k)(*[r[2 * part].data_ptr() for r in res])
+        bp = (C.c_void_p * k)(*[r[2 * part + 1].data_ptr() for r in res])
         L.call("mz_conv3x3_pack_many", wp, fp, bp, k, part, L.current_stream())
-    return [tuple(out[i, j] for j in range(out.shape[1])) for i in range(k)]
+    return res
 
 
-def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, packed_lo=None):
+def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, packed_lo=None, three_launches=False):
     """y = [relu]( [mask > 0 ?] (conv3x3(x) + bias [+ skip]) : 0 ) with the packed weight image (forward image: the convolution;
     data-gradient image applied to a grad_output: the input gradient).  x, skip, mask (n,128,8,8) f32 NCHW (mz_conv3x3_fused).
-    packed_lo (the matching lo image of pack_conv(split=True)): split precision, three launches accumulating in y --
-    conv(x hi, W hi) + bias + skip, + conv(x lo, W hi), epilogue(+ conv(x hi, W lo))."""
+    packed_lo (the matching lo image of pack_conv(split=True)): split precision -- ONE launch that forms the three products
+    W_hi x_hi + W_hi x_lo + W_lo x_hi from a hi and a lo image of x in LDS when the two images are pack_conv's stream (lo
+    36 stages behind hi), else three launches accumulating in y."""
     _check(x, "conv3x3 input")
     for t, name in ((skip, "skip"), (mask, "mask")):
         if t is not None:
@@ -111,6 +131,8 @@ def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, pa
     n, st, b = int(x.shape[0]), L.current_stream(), L.dptr(bias.detach() if bias is not None else None)
     if packed_lo is None:
         L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 0, L.dptr(skip), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
+    elif packed_lo.data_ptr() == packed.data_ptr() + 36 * 4096 * 2 and not three_launches:
+        L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 2, L.dptr(skip), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
     else:
         L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 0, L.dptr(skip), None, L.dptr(y), n, 0, st)
         L.call("mz_conv3x3_fused", L.dptr(packed), None, L.dptr(x), 1, L.dptr(y), None, L.dptr(y), n, 0, st)

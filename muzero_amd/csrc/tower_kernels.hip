@@ -867,8 +867,11 @@ struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; i
 // Epilogue (EPI bit 0: skip, bit 1: mask), all on (n,128,8,8) f32 NCHW tensors: y = [relu]( [mask > 0 ?] (acc [+ skip]) : 0 ).
 // That is the residual block's forward tail relu(h + conv(t)) and, in the backward pass, the ReLU gates and the skip path's
 // gradient: g_t = dgrad(g_pre) * (t > 0);  g_pre_prev = (g_pre + dgrad(g_t)) * (y_prev > 0) -- no elementwise pass of their own.
-template <int NJ, int EPI>   // NJ boards per workgroup: 8, or 4 (twice the workgroups for small batches)
+// X3 (x_part = 2, 4-board tiles only): split precision in ONE launch -- x goes into a hi and a lo image, a.w is the stream
+// [36 stages of W hi][36 of W lo][4 of padding], W_hi meets both images in one K loop (layer_mid's DUAL form), W_lo x_hi follows.
+template <int NJ, int EPI, bool X3 = false>   // NJ boards per workgroup: 8, or 4 (twice the workgroups for small batches)
 __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
+    static_assert(!X3 || NJ == 4, "two images fit for a 4-board tile only");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     constexpr int BOARDS = NJ, POS = 64 * NJ, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
     const int tid = threadIdx.x;
@@ -887,7 +890,19 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[c][k] = src[((c0 + c) * 8 + k) * 64];
-                if (a.x_part) {   // the rounding remainder x - bf16(x) (exact in f32): the second term of a split-precision product
+                if (X3) {   // both images: hi here, the remainders below
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t hi[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            hi[k] = pack_bf16(v[c][2 * k], v[c][2 * k + 1]);
+                            v[c][2 * k] -= bf16_up(hi[k] & 0xFFFFu);
+                            v[c][2 * k + 1] -= __uint_as_float(hi[k] & 0xFFFF0000u);
+                        }
+                        *reinterpret_cast<uint4 *>(row + (((cbase + c0 + c) ^ key) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                    }
+                } else if (a.x_part) {   // the rounding remainder x - bf16(x) (exact in f32): the second term of a split-precision product
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -899,12 +914,15 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    *reinterpret_cast<uint4 *>(row + (((cbase + c0 + c) ^ key) << 4)) =
+                    *reinterpret_cast<uint4 *>(row + (X3 ? X3_LO : 0) + (((cbase + c0 + c) ^ key) << 4)) =
                         make_uint4(pack_bf16(v[c][0], v[c][1]), pack_bf16(v[c][2], v[c][3]), pack_bf16(v[c][4], v[c][5]), pack_bf16(v[c][6], v[c][7]));
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < CHUNKS; ++c) *reinterpret_cast<uint4 *>(row + ((cbase + c) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            for (int c = 0; c < CHUNKS; ++c) {
+                *reinterpret_cast<uint4 *>(row + ((cbase + c) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+                if (X3) *reinterpret_cast<uint4 *>(row + X3_LO + ((cbase + c) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
@@ -919,7 +937,12 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = bv;
     }
     const Tower none{};
-    layer_mid<2, NJ>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
+    if constexpr (X3) {
+        layer_mid<2, 8, true>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);               // W_hi x_hi + W_hi x_lo
+        layer_mid<2, 4>(lds, a.w + N_STAGES * 512, nullptr, acc, nullptr, tid, none, 0);    // W_lo x_hi
+    } else {
+        layer_mid<2, NJ>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = posbase + 16 * j + p16;
@@ -1380,15 +1403,19 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
     int dev = 0, cus = 0;
     MZ_HIP(hipGetDevice(&dev));
     MZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const bool small = (n + 7) / 8 < cus;
+    MZ_REQUIRE(x_part >= 0 && x_part <= 2, "mz_conv3x3_fused: x_part must be 0, 1 or 2");
+    const bool small = x_part == 2 || (n + 7) / 8 < cus;
     const int64_t n_tiles = small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
     MZ_REQUIRE(mask != y, "mz_conv3x3_fused: mask aliases the output");   // skip may: every lane reads its own cells before it writes them
-    MZ_REQUIRE(x_part == 0 || x_part == 1, "mz_conv3x3_fused: x_part must be 0 or 1");
     const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu, skip, mask, (int)x_part};
     const dim3 grid((unsigned)n_tiles), block(512);
     const hipStream_t st = (hipStream_t)stream;
-    switch ((small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
+    switch ((x_part == 2 ? 8 : 0) | (small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
+        case 12: hipLaunchKernelGGL((k_conv3x3<4, 0, true>), grid, block, 0, st, a); break;
+        case 13: hipLaunchKernelGGL((k_conv3x3<4, 1, true>), grid, block, 0, st, a); break;
+        case 14: hipLaunchKernelGGL((k_conv3x3<4, 2, true>), grid, block, 0, st, a); break;
+        case 15: hipLaunchKernelGGL((k_conv3x3<4, 3, true>), grid, block, 0, st, a); break;
         case 0: hipLaunchKernelGGL((k_conv3x3<8, 0>), grid, block, 0, st, a); break;
         case 1: hipLaunchKernelGGL((k_conv3x3<8, 1>), grid, block, 0, st, a); break;
         case 2: hipLaunchKernelGGL((k_conv3x3<8, 2>), grid, block, 0, st, a); break;

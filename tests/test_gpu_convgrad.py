@@ -160,6 +160,11 @@ def test_split_precision_kernels_are_close_to_fp32():
     e3 = (conv3x3(x, pf, bias, packed_lo=pfl).double() - ref).norm().item() / ref.norm().item()
     print("conv: relative L2 error bf16 %.3g, bf16x3 %.3g" % (e1, e3))
     assert e3 <= 2e-5 and e3 <= e1 / 50
+    # one launch (hi / lo images of x in LDS, the weights' hi / lo stream) against the three accumulating launches: the same products
+    y1, y3 = conv3x3(x, pf, bias, packed_lo=pfl), conv3x3(x, pf, bias, packed_lo=pfl, three_launches=True)
+    assert (y1 - y3).norm().item() <= 1e-6 * y3.norm().item() and not torch.equal(y1, torch.zeros_like(y1))
+    e3b = (y3.double() - ref).norm().item() / ref.norm().item()
+    assert e3b <= 2e-5
     # the fused epilogue runs once, on the sum of the three products
     got = conv3x3(x, pf, bias, relu=True, skip=skip, mask=skip.relu(), packed_lo=pfl)
     want = torch.where(skip > 0, (ref + skip.double()).clamp_min(0), torch.zeros_like(ref))
