@@ -27,6 +27,16 @@ python3 tools/pmc_summary.py $(find $O/sq -name "t_counter_collection.csv" | hea
 step stamps
 timeout -k 10 200 python3 tools/tower_stamps.py 4096 2>&1 | grep -v amdgpu.ids > $O/tower_phase_stamps.txt || exit 1
 timeout -k 10 200 python3 tools/tower_bench.py 4096 2>&1 | grep -v amdgpu.ids > $O/tower_vs_miopen.txt || exit 1
+step split-precision tower kernel
+X="python3 tools/x3_engine_prof.py 4096 20"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x3s -o x -- $X > $O/x3_engine_under_rocprof.txt 2> $O/x3s.err || exit 1
+cp $(find $O/x3s -name "x_kernel_stats.csv" | head -1) $O/x3_kernel_stats.csv || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/x3f -o f -- $X > /dev/null 2> $O/x3f.err || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/x3w -o w -- $X > /dev/null 2> $O/x3w.err || exit 1
+python3 tools/pmc_hbm.py $(find $O/x3f -name "f_counter_collection.csv" | head -1) $(find $O/x3w -name "w_counter_collection.csv" | head -1) $O/x3_pmc_summary.json "ResArgs)=k_restower_x3" > /dev/null || exit 1
+timeout -k 10 100 python3 tools/restower_stamps.py 4096 2>&1 | grep -v amdgpu.ids > $O/restower_x3_phase_stamps.txt || exit 1
+timeout -k 10 100 python3 tools/restower_bench.py 4096 2>&1 | grep -v amdgpu.ids > $O/restower_x3_vs_chain_vs_miopen.txt || exit 1
+rm -rf $O/x3s $O/x3f $O/x3w
 step bench
 step training step kernel stats
 bash tools/train_gaps.sh hip > $O/train_hip_step_kernels.txt 2>&1 || exit 1   # steady-state window of the kernel trace: busy time per kernel
