@@ -55,6 +55,19 @@ def conv3x3_wgrad(xs, gs, dw, db=None, accumulate=False, x3=False):
     return dw, db
 
 
+def conv3x3_wgrad_unchecked(st, xs, gs, dw, db, x3=False):
+    """conv3x3_wgrad(accumulate=True) for callers that have already checked their tensors (train.DeferredWeightGrads.flush:
+    contiguous (n,128,8,8) f32 pairs from _TowerHip), on the stream handle st"""
+    k = len(xs)
+    nb = [x.shape[0] for x in xs]
+    ws = _workspace(dw.device, int(L.lib.mz_conv3x3_wgrad_workspace(sum(nb))))
+    rc = (L.lib.mz_conv3x3_wgrad_x3 if x3 else L.lib.mz_conv3x3_wgrad)(
+        (C.c_void_p * k)(*[x.data_ptr() for x in xs]), (C.c_void_p * k)(*[g.data_ptr() for g in gs]), (C.c_int64 * k)(*nb), k,
+        dw.data_ptr(), None if db is None else db.data_ptr(), 1, ws.data_ptr(), ws.numel(), st)
+    if rc != 0:
+        raise L.MzError("mz_conv3x3_wgrad failed (%d): %s" % (rc, L.lib.mz_last_error().decode()))
+
+
 PACKED_ELEMS = 40 * 4096   # MZ_CONV3X3_PACKED_BYTES / 2
 
 
@@ -137,6 +150,20 @@ def conv3x3(x, packed, bias=None, relu=False, out=None, skip=None, mask=None, pa
         L.call("mz_conv3x3_fused", L.dptr(packed), b, L.dptr(x), 0, L.dptr(skip), None, L.dptr(y), n, 0, st)
         L.call("mz_conv3x3_fused", L.dptr(packed), None, L.dptr(x), 1, L.dptr(y), None, L.dptr(y), n, 0, st)
         L.call("mz_conv3x3_fused", L.dptr(packed_lo), None, L.dptr(x), 0, L.dptr(y), L.dptr(mask), L.dptr(y), n, 1 if relu else 0, st)
+    return y
+
+
+def conv3x3_unchecked(st, x, packed, bias=None, relu=False, skip=None, mask=None, x3=False):
+    """conv3x3 for callers that have already checked their tensors (train._TowerHip: 66 calls per training step, where the
+    checks and the stream lookup of conv3x3 cost more host time than the launch): st = L.current_stream() taken once by the
+    caller, packed = a forward or data-gradient image of pack_conv, x3 = split precision in one launch (packed is then the hi
+    image of pack_conv(split=True), whose lo image follows 36 stages behind it)."""
+    y = torch.empty_like(x)
+    rc = L.lib.mz_conv3x3_fused(packed.data_ptr(), None if bias is None else bias.data_ptr(), x.data_ptr(), 2 if x3 else 0,
+                                None if skip is None else skip.data_ptr(), None if mask is None else mask.data_ptr(), y.data_ptr(),
+                                x.shape[0], 1 if relu else 0, st)
+    if rc != 0:
+        raise L.MzError("mz_conv3x3_fused failed (%d): %s" % (rc, L.lib.mz_last_error().decode()))
     return y
 
 

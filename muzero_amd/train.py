@@ -177,16 +177,25 @@ class DeferredWeightGrads:
 
     @torch.no_grad()
     def flush(self):
+        st = None
         for conv, sink in self.sinks.values():
             if not sink:
                 continue
             has_b = conv.bias is not None
             if self._is_tower_conv(conv, sink[0][0]):
-                from .convgrad import conv3x3_wgrad
+                from .convgrad import conv3x3_wgrad, conv3x3_wgrad_unchecked
                 for prm in (conv.weight, conv.bias):
                     if prm is not None and prm.grad is None:
                         prm.grad = torch.zeros_like(prm)
-                conv3x3_wgrad([x.contiguous() for x, _ in sink], [g for _, g in sink], conv.weight.grad, conv.bias.grad if has_b else None, accumulate=True, x3=self.x3)
+                gw, gb = conv.weight.grad, conv.bias.grad if has_b else None
+                if (len(sink) <= 8 and gw.is_contiguous() and gw.dtype == torch.float32 and (gb is None or gb.is_contiguous())
+                        and all(x.is_contiguous() and g.is_contiguous() and x.shape == g.shape and x.dtype == g.dtype == torch.float32 for x, g in sink)):
+                    if st is None:
+                        from . import _lib as L
+                        st = L.current_stream()
+                    conv3x3_wgrad_unchecked(st, [x for x, _ in sink], [g for _, g in sink], gw, gb, x3=self.x3)
+                else:   # the checked call says what is wrong
+                    conv3x3_wgrad([x.contiguous() for x, _ in sink], [g for _, g in sink], gw, gb, accumulate=True, x3=self.x3)
                 sink.clear()
                 continue
             X = torch.cat([x for x, _ in sink]) if len(sink) > 1 else sink[0][0]
@@ -211,15 +220,16 @@ class _TowerHip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, blocks, dw):
-        from .convgrad import conv3x3
-        y = h0.contiguous()
+        from . import _lib as L
+        from .convgrad import conv3x3_unchecked as conv
+        y = h0.contiguous()        # (n,128,8,8) f32 on the GPU: _tower_deferred has checked (dw._is_tower_conv)
+        st, x3 = L.current_stream(), dw.x3
         saved, packs = [y], []
         for blk in blocks:
             c1, c2 = blk.block[0], blk.block[2]
             p1, p2 = dw.pack(c1), dw.pack(c2)
-            lo1, lo2 = (p1[2], p2[2]) if len(p1) > 2 else (None, None)
-            t = conv3x3(y, p1[0], c1.bias, relu=True, packed_lo=lo1)
-            y = conv3x3(t, p2[0], c2.bias, relu=True, skip=y, packed_lo=lo2)
+            t = conv(st, y, p1[0], c1.bias, relu=True, x3=x3)
+            y = conv(st, t, p2[0], c2.bias, relu=True, skip=y, x3=x3)
             saved += [t, y]
             packs.append((p1, p2))
         ctx.save_for_backward(*saved)
@@ -228,17 +238,18 @@ class _TowerHip(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        from .convgrad import conv3x3
+        from . import _lib as L
+        from .convgrad import conv3x3_unchecked as conv
+        st, x3 = L.current_stream(), ctx.dw.x3
         saved = ctx.saved_tensors                                  # h0, t1, y1, t2, y2, t3, y3
         g_pre = torch.ops.aten.threshold_backward(g.contiguous(), saved[-1], 0)   # the last block's ReLU gate
         for k in range(len(ctx.blocks) - 1, -1, -1):
             c1, c2 = ctx.blocks[k].block[0], ctx.blocks[k].block[2]
             p1, p2 = ctx.packs[k]
             y_prev, t = saved[2 * k], saved[2 * k + 1]
-            lo1, lo2 = (p1[3], p2[3]) if len(p1) > 2 else (None, None)
-            g_t = conv3x3(g_pre, p2[1], mask=t, packed_lo=lo2)
+            g_t = conv(st, g_pre, p2[1], mask=t, x3=x3)
             ctx.dw.park(c2, t, g_pre)
-            g_prev = conv3x3(g_t, p1[1], skip=g_pre, mask=y_prev if k > 0 else None, packed_lo=lo1)   # h0's own gate belongs to the caller's ReLU
+            g_prev = conv(st, g_t, p1[1], skip=g_pre, mask=y_prev if k > 0 else None, x3=x3)   # h0's own gate belongs to the caller's ReLU
             ctx.dw.park(c1, y_prev, g_t)
             g_pre = g_prev
         return g_pre, None, None
