@@ -77,6 +77,9 @@ def pack_conv(weight, out=None, split=False):
     w = weight.detach()
     if not w.is_cuda or w.dtype != torch.float32 or tuple(w.shape) != (128, 128, 3, 3) or not w.is_contiguous():
         raise L.MzError("pack_conv: need a contiguous cuda float32 (128,128,3,3) weight")
+    want = (2, STREAM_ELEMS if split else PACKED_ELEMS)
+    if out is not None and (tuple(out.shape) != want or out.dtype != torch.bfloat16 or not out.is_contiguous() or out.device != w.device):
+        raise L.MzError("pack_conv: out must be a contiguous bfloat16 %s tensor on the weight's device" % (want,))
     if not split:
         if out is None:
             out = torch.empty((2, PACKED_ELEMS), dtype=torch.bfloat16, device=w.device)
