@@ -211,19 +211,23 @@ typedef __attribute__((ext_vector_type(4))) float acc16_t;
 // at X3_LO) that accumulate into the same NJ / 2 accumulators: one weight stage feeds W x_hi and W x_lo, 32 MFMAs per 12 fragment
 // reads like the 8-board tile, on a 4-board tile.
 constexpr int X3_LO = 65536;         // byte offset of the lo image
-template <int MODE, int NJ = 8, bool DUAL = false>
-__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[4][DUAL ? NJ / 2 : NJ],
+// NI = output-channel tiles per wave: 4 (wave = 64 co, two co halves x four position groups), or 2 (wave = 32 co, four co quarters x
+// two position groups: with NJ = 4 a 2-board tile -- the training convolution when even 4-board tiles leave CUs idle; MODE 2 only)
+template <int MODE, int NJ = 8, bool DUAL = false, int NI = 4>
+__device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ wp, const uint4 *__restrict__ w_last, acc16_t (&acc)[NI][DUAL ? NJ / 2 : NJ],
                                           const float *__restrict__ bias_next, int tid, const Tower &tw, int stamp_id, int xoff = OFF_X) {
     // xoff: byte offset of the image the K loop READS (the split-precision tower keeps two: k_restower_x3); the MODE 0 / 1
     // epilogues below work on the image at OFF_X
     const int w = tid >> 6, lane = tid & 63, c16 = lane & 15, kc = lane >> 4, p16 = col_cell(c16);
     constexpr int NA = DUAL ? NJ / 2 : NJ;   // accumulator tiles per wave
-    const int cobase = 64 * (w & 1), posbase = 16 * NA * (w >> 1);
+    constexpr int CW = 8 / NI;               // waves across the 128 output channels
+    static_assert((NI == 4 || (NI == 2 && MODE == 2)) && NJ >= 4, "layer_mid shapes");
+    const int cobase = 16 * NI * (w & (CW - 1)), posbase = 16 * NA * (w / CW);
 
     // weights: address = ring buffer + co * 64 + ((kc ^ key(co)) << 4), key = perm[(co >> 2) & 3], perm = {0, 2, 3, 1}
-    int waddr[4];
+    int waddr[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int co = cobase + 16 * i + c16;
         waddr[i] = OFF_W + co * 64 + ((kc ^ ((0x78 >> (((co >> 2) & 3) * 2)) & 3)) << 4);
     }
@@ -249,13 +253,13 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     };
     auto bfrag = [&](int j) { return lds_frag(lds + ((j & 3) == 0 ? at : ((j & 3) == 3 ? ab : am)) + (j & (NA - 1)) * 4096 + (j / NA) * X3_LO); };
 
-    bf16x8 a[2][4], b[4];
+    bf16x8 a[2][NI], b[4];
     set_tap(0, 0);
     set_kq(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) b[j] = bfrag(j);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[0][i] = lds_frag(lds + waddr[i]);
+    for (int i = 0; i < NI; ++i) a[0][i] = lds_frag(lds + waddr[i]);
 
     // 3 trips x 12 stages (3 taps): ring index, channel quarter and the register-set parity are compile-time constants
     // and the body is branch-free.  The last trip prefetches "tap 9" fragments (any address is a legal LDS read; they are
@@ -268,21 +272,23 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
         for (int ss = 0; ss < 12; ++ss) {
             // all but the youngest DMA (stage st + 2, issued one iteration ago) have landed: stage st + 1 is complete
             asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-            const bf16x8(&ca)[4] = a[ss & 1];
-            bf16x8(&na)[4] = a[(ss + 1) & 1];
+            const bf16x8(&ca)[NI] = a[ss & 1];
+            bf16x8(&na)[NI] = a[(ss + 1) & 1];
             const int nbuf = ((ss + 1) & 3) * WSTAGE_BYTES;   // 12 = 0 (mod 4, mod 2): ss + 1 indexes like st + 1
 #define MZ_FENCE() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                acc[0][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[0], b[j & 3], acc[0][j & (NA - 1)], 0, 0, 0);
-                acc[1][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[1], b[j & 3], acc[1][j & (NA - 1)], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI / 2; ++i)
+                    acc[i][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], b[j & 3], acc[i][j & (NA - 1)], 0, 0, 0);
                 MZ_FENCE();
                 b[(j + 3) & 3] = bfrag((j + 3) & (NJ - 1));   // j <= 4: this stage's tile j + 3; j >= 5: the next stage's tile j - 5 (its addresses are set behind j = 4)
                 MZ_FENCE();
-                acc[2][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[2], b[j & 3], acc[2][j & (NA - 1)], 0, 0, 0);
-                acc[3][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[3], b[j & 3], acc[3][j & (NA - 1)], 0, 0, 0);
+#pragma unroll
+                for (int i = NI / 2; i < NI; ++i)
+                    acc[i][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], b[j & 3], acc[i][j & (NA - 1)], 0, 0, 0);
                 MZ_FENCE();
-                if (j < 4) {
+                if (j < NI) {
                     na[j] = lds_frag(lds + nbuf + waddr[j]);
                     MZ_FENCE();
                 }
@@ -307,7 +313,8 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     }
 
     MZ_STAMP(tw, stamp_id);
-    if (MODE == 2) return;   // the training convolution (k_conv3x3): the caller stores the accumulators; nothing touches the image
+    // MODE 2 (the training convolution k_conv3x3, the split-precision tower): the caller stores the accumulators; nothing touches the image
+    if constexpr (MODE != 2) {
     // the next layer's bias in the accumulator layout: channels cobase + 16 i + 4 kc + 0..3
     f32x4 bn[4];
 #pragma unroll
@@ -340,6 +347,7 @@ __device__ __forceinline__ void layer_mid(char *lds, const uint4 *__restrict__ w
     // raw barrier (LDS only): the weight DMAs still in flight belong to the NEXT layer's stages 1 and 2 (or are the last
     // convolution's weights) and are retired by the next counted waits; __syncthreads() would stall every layer boundary on them
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 }
 
 // ---- first layer: input planes (global, NCHW) -> the image.  Its operands are staged INSIDE the (not yet written) image:
@@ -869,11 +877,12 @@ struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; i
 // gradient: g_t = dgrad(g_pre) * (t > 0);  g_pre_prev = (g_pre + dgrad(g_t)) * (y_prev > 0) -- no elementwise pass of their own.
 // X3 (x_part = 2, 4-board tiles only): split precision in ONE launch -- x goes into a hi and a lo image, a.w is the stream
 // [36 stages of W hi][36 of W lo][4 of padding], W_hi meets both images in one K loop (layer_mid's DUAL form), W_lo x_hi follows.
-template <int NJ, int EPI, bool X3 = false>   // NJ boards per workgroup: 8, or 4 (twice the workgroups for small batches)
+// NI = 2 (with NJ = 4): 2-board tiles, four waves across the output channels -- for batches where 4-board tiles leave CUs idle
+template <int NJ, int EPI, bool X3 = false, int NI = 4>   // NJ * NI / 4 boards per workgroup: 8, 4 or 2
 __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
-    static_assert(!X3 || NJ == 4, "two images fit for a 4-board tile only");
+    static_assert((!X3 || NJ == 4) && (NI == 4 || (NI == 2 && NJ == 4 && !X3)), "tile shapes");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-    constexpr int BOARDS = NJ, POS = 64 * NJ, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
+    constexpr int BOARDS = NJ * NI / 4, POS = 64 * BOARDS, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
     const int tid = threadIdx.x;
     const int64_t board0 = (int64_t)blockIdx.x * BOARDS;
     mid_prologue(lds, a.w, tid);
@@ -928,10 +937,11 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's DMA pieces
     __syncthreads();
     const int w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15);
-    const int cobase = 64 * (w & 1), posbase = 16 * NJ * (w >> 1);
-    acc16_t acc[4][NJ];
+    constexpr int CW = 8 / NI;   // waves across the output channels (layer_mid)
+    const int cobase = 16 * NI * (w & (CW - 1)), posbase = 16 * NJ * (w / CW);
+    acc16_t acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + cobase + 16 * i + 4 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = bv;
@@ -941,7 +951,7 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
         layer_mid<2, 8, true>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);               // W_hi x_hi + W_hi x_lo
         layer_mid<2, 4>(lds, a.w + N_STAGES * 512, nullptr, acc, nullptr, tid, none, 0);    // W_lo x_hi
     } else {
-        layer_mid<2, NJ>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
+        layer_mid<2, NJ, false, NI>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -949,21 +959,21 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
         const int64_t b = board0 + (q >> 6);
         if (b < a.n_boards) {
             const int64_t o = (b * 128 + cobase + 4 * kc) * 64 + (q & 63);
-            float sk[4][4], mk[4][4];
+            float sk[NI][4], mk[NI][4];
             if (EPI & 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sk[i][e] = a.skip[o + (16 * i + e) * 64];
             }
             if (EPI & 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) mk[i][e] = a.mask[o + (16 * i + e) * 64];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[i][j][e];
@@ -1405,13 +1415,18 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
     MZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     MZ_REQUIRE(x_part >= 0 && x_part <= 2, "mz_conv3x3_fused: x_part must be 0, 1 or 2");
     const bool small = x_part == 2 || (n + 7) / 8 < cus;
-    const int64_t n_tiles = small ? (n + 3) / 4 : (n + 7) / 8;
+    const bool tiny = x_part != 2 && (n + 3) / 4 < cus;   // 2-board tiles: even 4-board tiles would leave CUs idle
+    const int64_t n_tiles = tiny ? (n + 1) / 2 : small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
     MZ_REQUIRE(mask != y, "mz_conv3x3_fused: mask aliases the output");   // skip may: every lane reads its own cells before it writes them
     const ConvArgs a{(const uint4 *)packed, bias, x, y, n, relu, skip, mask, (int)x_part};
     const dim3 grid((unsigned)n_tiles), block(512);
     const hipStream_t st = (hipStream_t)stream;
-    switch ((x_part == 2 ? 8 : 0) | (small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
+    switch ((tiny ? 16 : 0) | (x_part == 2 ? 8 : 0) | (small ? 4 : 0) | (skip ? 1 : 0) | (mask ? 2 : 0)) {
+        case 20: hipLaunchKernelGGL((k_conv3x3<4, 0, false, 2>), grid, block, 0, st, a); break;
+        case 21: hipLaunchKernelGGL((k_conv3x3<4, 1, false, 2>), grid, block, 0, st, a); break;
+        case 22: hipLaunchKernelGGL((k_conv3x3<4, 2, false, 2>), grid, block, 0, st, a); break;
+        case 23: hipLaunchKernelGGL((k_conv3x3<4, 3, false, 2>), grid, block, 0, st, a); break;
         case 12: hipLaunchKernelGGL((k_conv3x3<4, 0, true>), grid, block, 0, st, a); break;
         case 13: hipLaunchKernelGGL((k_conv3x3<4, 1, true>), grid, block, 0, st, a); break;
         case 14: hipLaunchKernelGGL((k_conv3x3<4, 2, true>), grid, block, 0, st, a); break;

@@ -115,7 +115,7 @@ def test_training_gradients_with_hip_convolutions_match_the_fp32_step():
     assert all(torch.isfinite(v).all() for v in got.values())
 
 
-@pytest.mark.parametrize("n", [1, 8, 13, 512, 2051])   # below / above one 8-board tile per CU: 4-board and 8-board tiles
+@pytest.mark.parametrize("n", [1, 8, 13, 512, 1023, 1501, 2051])   # 2-board tiles (fewer than one 4-board tile per CU), 4-board tiles, 8-board tiles
 def test_conv3x3_forward_and_data_gradient_match_fp64_on_bf16_values(n):
     from muzero_amd.convgrad import conv3x3, pack_conv
     g = torch.Generator(device="cuda").manual_seed(n)
