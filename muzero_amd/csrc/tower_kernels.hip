@@ -880,7 +880,7 @@ struct ConvArgs { const uint4 *w; const float *bias; const float *x; float *y; i
 // NI = 2 (with NJ = 4): 2-board tiles, four waves across the output channels -- for batches where 4-board tiles leave CUs idle
 template <int NJ, int EPI, bool X3 = false, int NI = 4>   // NJ * NI / 4 boards per workgroup: 8, 4 or 2
 __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
-    static_assert((!X3 || NJ == 4) && (NI == 4 || (NI == 2 && NJ == 4 && !X3)), "tile shapes");
+    static_assert((!X3 || NJ == 4) && (NI == 4 || (NI == 2 && NJ == 4)), "tile shapes");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     constexpr int BOARDS = NJ * NI / 4, POS = 64 * BOARDS, SPLIT = 512 / POS, CHUNKS = 16 / SPLIT;   // SPLIT threads share a position's 16 chunks
     const int tid = threadIdx.x;
@@ -948,8 +948,8 @@ __global__ void __launch_bounds__(512) k_conv3x3(ConvArgs a) {
     }
     const Tower none{};
     if constexpr (X3) {
-        layer_mid<2, 8, true>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);               // W_hi x_hi + W_hi x_lo
-        layer_mid<2, 4>(lds, a.w + N_STAGES * 512, nullptr, acc, nullptr, tid, none, 0);    // W_lo x_hi
+        layer_mid<2, 8, true, NI>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);                      // W_hi x_hi + W_hi x_lo
+        layer_mid<2, 4, false, NI>(lds, a.w + N_STAGES * 512, nullptr, acc, nullptr, tid, none, 0);    // W_lo x_hi
     } else {
         layer_mid<2, NJ, false, NI>(lds, a.w, nullptr, acc, nullptr, tid, none, 0);
     }
@@ -1415,7 +1415,7 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
     MZ_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     MZ_REQUIRE(x_part >= 0 && x_part <= 2, "mz_conv3x3_fused: x_part must be 0, 1 or 2");
     const bool small = x_part == 2 || (n + 7) / 8 < cus;
-    const bool tiny = x_part != 2 && (n + 3) / 4 < cus;   // 2-board tiles: even 4-board tiles would leave CUs idle
+    const bool tiny = (n + 3) / 4 < cus;   // 2-board tiles: even 4-board tiles would leave CUs idle
     const int64_t n_tiles = tiny ? (n + 1) / 2 : small ? (n + 3) / 4 : (n + 7) / 8;
     MZ_REQUIRE(n_tiles <= 0x7fffffff, "mz_conv3x3_forward: too many boards");
     MZ_REQUIRE(mask != y, "mz_conv3x3_fused: mask aliases the output");   // skip may: every lane reads its own cells before it writes them
@@ -1427,6 +1427,10 @@ extern "C" int mz_conv3x3_fused(const void *packed, const float *bias, const flo
         case 21: hipLaunchKernelGGL((k_conv3x3<4, 1, false, 2>), grid, block, 0, st, a); break;
         case 22: hipLaunchKernelGGL((k_conv3x3<4, 2, false, 2>), grid, block, 0, st, a); break;
         case 23: hipLaunchKernelGGL((k_conv3x3<4, 3, false, 2>), grid, block, 0, st, a); break;
+        case 28: hipLaunchKernelGGL((k_conv3x3<4, 0, true, 2>), grid, block, 0, st, a); break;
+        case 29: hipLaunchKernelGGL((k_conv3x3<4, 1, true, 2>), grid, block, 0, st, a); break;
+        case 30: hipLaunchKernelGGL((k_conv3x3<4, 2, true, 2>), grid, block, 0, st, a); break;
+        case 31: hipLaunchKernelGGL((k_conv3x3<4, 3, true, 2>), grid, block, 0, st, a); break;
         case 12: hipLaunchKernelGGL((k_conv3x3<4, 0, true>), grid, block, 0, st, a); break;
         case 13: hipLaunchKernelGGL((k_conv3x3<4, 1, true>), grid, block, 0, st, a); break;
         case 14: hipLaunchKernelGGL((k_conv3x3<4, 2, true>), grid, block, 0, st, a); break;
