@@ -309,7 +309,7 @@ def bench_train(args, device, rec):
             "k_conv3x3": {"boards": B, "us_per_launch": us_conv, "tflops": conv_flop / us_conv / 1e6, "frac_of_bf16_peak": conv_flop / us_conv / 1e6 / BF16_PEAK_TFLOPS,
                           "hbm_gbps_fp32_io": B * 65536 / us_conv / 1e3, "frac_of_hbm_peak": B * 65536 / us_conv / 1e3 / HBM_PEAK_GBPS,
                           "note": "forward / data gradient of one 128->128 convolution, fp32 NCHW in and out (64 KB per board = 295 FLOP/B: as HBM-bound as "
-                                  "MFMA-bound); at this batch 128 workgroups of 4 boards, one tile each: load, K loop and store phases do not overlap"},
+                                  "MFMA-bound); at this batch 256 workgroups of 2 boards (4- and 8-board tiles from 1024 / 2048 boards on), one tile each: load, K loop and store phases do not overlap"},
             "k_conv_wgrad+k_wgrad_reduce": {"boards": B * K, "us_per_launch": us_wgrad, "tflops": K * conv_flop / us_wgrad / 1e6,
                                             "frac_of_bf16_peak": K * conv_flop / us_wgrad / 1e6 / BF16_PEAK_TFLOPS,
                                             "hbm_gbps_fp32_operands": B * K * 98304 / us_wgrad / 1e3, "frac_of_hbm_peak": B * K * 98304 / us_wgrad / 1e3 / HBM_PEAK_GBPS,
