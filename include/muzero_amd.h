@@ -473,7 +473,7 @@ int mz_conv3x3_fused(const void *packed, const float *bias, const float *x, int3
  *   One convolution = three launches accumulating through skip (which may alias y):
  *       y  = conv(x hi, W hi) + bias [+ residual skip];   y += conv(x lo, W hi);   y = epilogue(y + conv(x hi, W lo))
  *   or ONE launch, x_part = 2: packed then points at a stream [36 stages of the hi image][36 of the lo image][4 of padding] (pack the
- *   hi image to p, then the lo image to p + 36 * 4096 * 2 bytes); x goes into a hi and a lo image in LDS (4-board tiles), W_hi meets
+ *   hi image to p, then the lo image to p + 36 * 4096 * 2 bytes); x goes into a hi and a lo image in LDS (4- or 2-board tiles), W_hi meets
  *   both in one K loop, W_lo x_hi follows, the epilogue runs once.
  *   mz_conv3x3_wgrad_x3 forms the three products inside one pass over the operands. */
 int mz_conv3x3_pack_part(const float *w, void *packed_fwd, void *packed_bwd, int32_t part, void *stream);
