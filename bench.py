@@ -106,15 +106,16 @@ def newest_profile(name):
     return None
 
 
-def pmc_traffic_src(kernel):
+def pmc_traffic_src(kernel, name="pmc_summary.json"):
     """(bytes per launch, the committed file they were read from) -- the number is NOT measured in this run"""
     pdir = os.path.join(ROOT, "profiles")
     for r in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
-        f = os.path.join(pdir, r, "pmc_summary.json")
+        f = os.path.join(pdir, r, name)
         if os.path.exists(f):
             rec = json.load(open(f)).get(kernel)
             if rec and rec.get("hbm_bytes_per_launch"):
-                return rec["hbm_bytes_per_launch"], "profiles/%s/pmc_summary.json (rocprofv3 --pmc passes of this command, committed; not measured in this run)" % r
+                return rec["hbm_bytes_per_launch"], "profiles/%s/%s (rocprofv3 --pmc passes of %s, committed; not measured in this run)" % (
+                    r, name, "this command" if name == "pmc_summary.json" else "tools/x3_engine_prof.py")
     return None, None
 
 
@@ -694,6 +695,8 @@ def main():
                               "skip path in fp32 registers) with the prediction heads in plain fp32 behind it (mz_inference_x3_forward)",
                     roofline={"bound": "mfma", "achieved": 3 * tfx, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": 3 * tfx / BF16_PEAK_TFLOPS,
                               "us_per_launch_sequence": msx * 1e3, "fp32_grade_tflops": tfx,
+                              "traffic": pmc_traffic_src("k_restower_x3", "x3_pmc_summary.json")[0],
+                              "traffic_source": pmc_traffic_src("k_restower_x3", "x3_pmc_summary.json")[1],
                               "note": "bf16 MFMA work = 3 x the network's FLOPs, one launch per inference (tower + heads)"},
                     agreement_with_fp32_search=visit_agreement(fp32_visits, x3_visits))
                 del engx, netx
