@@ -1157,6 +1157,12 @@ __global__ void __launch_bounds__(512) k_restower_x3(ResArgs a) {
         MZ_STAMP(none, 4 + 3 * l);
     }
     if (FULL) {
+        // (the lane's indices are derived again from an opaque copy of the thread id: kept live across the K loops they were spilled)
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int tid = t2, w = tid >> 6, lane = tid & 63, kc = lane >> 4, p16 = col_cell(lane & 15), posbase = 64 * (w >> 1);
+        const int64_t b = board0 + (w >> 1);
+        const bool live = b < a.n_boards;
         // last convolution, as layer_last: the nine taps in the M dimension (P[tap * 8 + plane][pos], K = 128), then every lane sums
         // the nine shifted taps of one cell.  Even waves take their board, odd waves only keep the barriers.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the K loop's last prefetches (padding stages): the ring is dead
