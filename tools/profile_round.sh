@@ -37,6 +37,8 @@ python3 tools/pmc_hbm.py $(find $O/x3f -name "f_counter_collection.csv" | head -
 timeout -k 10 100 python3 tools/restower_stamps.py 4096 2>&1 | grep -v amdgpu.ids > $O/restower_x3_phase_stamps.txt || exit 1
 timeout -k 10 100 python3 tools/restower_bench.py 4096 2>&1 | grep -v amdgpu.ids > $O/restower_x3_vs_chain_vs_miopen.txt || exit 1
 rm -rf $O/x3s $O/x3f $O/x3w
+# the bench line reads its `traffic` fields from profiles/<round>/: give it THIS call's PMC summaries
+mkdir -p profiles/$R && cp $O/pmc_summary.json $O/x3_pmc_summary.json profiles/$R/ || exit 1
 step bench
 step training step kernel stats
 bash tools/train_gaps.sh hip > $O/train_hip_step_kernels.txt 2>&1 || exit 1   # steady-state window of the kernel trace: busy time per kernel
