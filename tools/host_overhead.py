@@ -1,3 +1,4 @@
+"""host-side cost of the convolution wrappers against the raw ctypes call (why train._TowerHip uses conv3x3_unchecked): python tools/host_overhead.py"""
 import sys, time, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from muzero_amd.convgrad import conv3x3, pack_conv, conv3x3_wgrad
