@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0, "/root/repo")
+"""robustness probe of the split-precision kernels on extreme inputs"""
+import sys; import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from muzero_amd.convgrad import conv3x3, conv3x3_wgrad, pack_conv
 g = torch.Generator(device="cuda").manual_seed(1)
