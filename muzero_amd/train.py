@@ -335,6 +335,8 @@ def update_weights(optimizer, network, batch, bucket=None, group=None, amp_dtype
             if batched is None:   # the GPU organisation where it pays: on a GPU, in the reference's fp32 arithmetic
                 batched = next(network.parameters()).is_cuda and os.environ.get("MZ_TRAIN_PLAIN") != "1"
             if hip_convs:
+                if not next(network.parameters()).is_cuda:   # no CPU stand-in for the HIP kernels
+                    raise RuntimeError("update_weights(hip_convs=%r) needs the network on a GPU: the hand-written convolution kernels have no CPU fallback" % (hip_convs,))
                 batched = True
             dw = DeferredWeightGrads(hip=hip_convs if hip_convs else False) if batched else None
             p_loss, v_loss = muzero_loss_batched(network, batch, dw) if batched else muzero_loss(network, batch)

@@ -233,3 +233,18 @@ def test_checkpoint_cross_loading_verdict_is_committed_and_clean(golden_dir):
     v = json.load(open(os.path.join(golden_dir, "checkpoint_xload_verdict.json")))
     assert v["cases"] >= 8 and v["reference_file_loaded_by_build"] == v["build_file_loaded_by_reference"] == v["cases"]
     assert v["outputs_compared"] == 12 * v["cases"] and v["outputs_not_bit_equal"] == 0
+
+
+def test_hip_convs_refuse_a_cpu_network():
+    """the training step's hand-written convolution kernels have no CPU stand-in: asking for them on a CPU network raises"""
+    import pytest
+    import torch
+    from muzero_amd import train as T
+    from muzero_amd.network import Network
+    net = Network()
+    opt = T.make_optimizer(net)
+    B, K = 2, 2
+    batch = (torch.zeros(B, 9, 8, 8), torch.zeros(K, B, 2, 8, 8), torch.zeros(K + 1, B), torch.full((K + 1, B, 65), 1 / 65))
+    for mode in (True, "x3"):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            T.update_weights(opt, net, batch, hip_convs=mode)
